@@ -1,0 +1,111 @@
+"""Point ``(x, y)`` with lazily evaluated problem data.
+
+A stand-in for the reference's ``Iterate`` (``pygradflow/iterate.py:19-110``)
+restricted to what the Newton/KKT path consumes: ``x, y, problem, params,
+eval`` and the cached ``obj_grad / cons / cons_jac / lag_hess`` plus the
+derived ``aug_lag_deriv_*``.  The step solver never *requires* this class: it
+accepts any object with this surface (in particular the reference's own
+``Iterate``) and builds the next point with ``type(iterate)(...)``.
+"""
+
+from __future__ import annotations
+
+import functools
+
+import numpy as np
+import scipy.sparse as sps
+
+
+def _frozen(a: np.ndarray) -> np.ndarray:
+    a.flags.writeable = False
+    return a
+
+
+class DirectEvaluator:
+    """Calls the problem callbacks, casting to ``params.dtype``
+    (cf. ``SimpleEvaluator``, reference ``pygradflow/eval.py:107-127``)."""
+
+    def __init__(self, problem, params):
+        self.problem = problem
+        self.dtype = params.dtype
+
+    def obj(self, x):
+        return self.problem.obj(x)
+
+    def obj_grad(self, x):
+        return np.asarray(self.problem.obj_grad(x), dtype=self.dtype)
+
+    def cons(self, x):
+        if self.problem.num_cons == 0:
+            return np.zeros((0,), dtype=self.dtype)
+        return np.asarray(self.problem.cons(x), dtype=self.dtype)
+
+    def cons_jac(self, x):
+        if self.problem.num_cons == 0:
+            return sps.csr_matrix((0, self.problem.num_vars), dtype=self.dtype)
+        return self.problem.cons_jac(x)
+
+    def lag_hess(self, x, y):
+        return self.problem.lag_hess(x, y)
+
+
+class Iterate:
+    def __init__(self, problem, params, x, y, eval=None):
+        if x.shape != (problem.num_vars,) or y.shape != (problem.num_cons,):
+            raise ValueError("iterate shape mismatch")
+        self.problem = problem
+        self.params = params
+        self.x = _frozen(np.array(x, copy=True))
+        self.y = _frozen(np.array(y, copy=True))
+        self.eval = eval if eval is not None else DirectEvaluator(problem, params)
+
+    @property
+    def z(self):
+        return np.concatenate((self.x, self.y))
+
+    @functools.cached_property
+    def obj(self):
+        return self.eval.obj(self.x)
+
+    @functools.cached_property
+    def obj_grad(self):
+        return _frozen(np.array(self.eval.obj_grad(self.x)))
+
+    @functools.cached_property
+    def cons(self):
+        return _frozen(np.array(self.eval.cons(self.x)))
+
+    @functools.cached_property
+    def cons_jac(self):
+        return self.eval.cons_jac(self.x)
+
+    def lag_hess(self, y):
+        return self.eval.lag_hess(self.x, y)
+
+    # derived quantities, reference iterate.py:91-110 ----------------------
+    def aug_lag_deriv_x(self, rho):
+        return self.obj_grad + self.cons_jac.T.dot(rho * self.cons + self.y)
+
+    def aug_lag_deriv_y(self):
+        return self.cons
+
+    def aug_lag_deriv_xy(self):
+        return self.cons_jac
+
+    def aug_lag_deriv_xx(self, rho):
+        mult = self.y + rho * self.cons
+        hess = self.lag_hess(mult)
+        if rho == 0.0:
+            return hess
+        jac = self.cons_jac
+        return hess + rho * (jac.T @ jac)
+
+    def dist(self, other):
+        return float(np.sqrt(np.sum((self.x - other.x) ** 2) + np.sum((self.y - other.y) ** 2)))
+
+    def check_eval(self):
+        self.obj
+        self.obj_grad
+        if self.problem.num_cons > 0:
+            self.cons
+            self.cons_jac

@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Generate golden vectors for the Newton/KKT hot path FROM THE REFERENCE.
+
+Runs only in the build container (needs ``/root/reference``; nothing from it
+is copied): it imports the reference's pure-Python modules, drives
+``newton_method(...).step(...)`` (reference ``pygradflow/newton.py:307-323``)
+on small problems and stores, per Newton step, the evaluated inputs the path
+consumed and every intermediate the path produced.  The resulting
+``tests/golden/*.npz`` files are data only (arrays); they travel to the GPU
+box, the reference does not.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
+"""
+
+import os
+import sys
+
+import numpy as np
+import scipy.sparse as sps
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("PGF_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, REPO)
+
+from pygradflow.iterate import Iterate  # noqa: E402  (reference)
+from pygradflow.newton import newton_method  # noqa: E402
+from pygradflow.params import NewtonType, Params  # noqa: E402
+from pygradflow.linear_solver import linear_solver  # noqa: E402
+from pygradflow.params import LinearSolverType  # noqa: E402
+from pygradflow.implicit_func import ImplicitFunc  # noqa: E402
+
+from pygradflow_amd import problems as P  # noqa: E402  (ours; duck-typed)
+
+OUT = os.path.join(REPO, "tests", "golden")
+POLICIES = ["Simplified", "Full", "ActiveSet"]
+
+
+def _dense(mat):
+    return mat.toarray() if sps.issparse(mat) else np.asarray(mat)
+
+
+def _margin(p, lb, ub):
+    """Smallest distance of p to either mask threshold (finite ones only)."""
+    with np.errstate(invalid="ignore"):
+        d = np.concatenate([np.abs(p - (lb - 1e-8)), np.abs(p - (ub + 1e-8))])
+    d = d[np.isfinite(d)]
+    return d.min() if d.size else np.inf
+
+
+def run_case(name, problem, x0, y0, dt, rho, steps, tau=None, policies=POLICIES,
+             store_problem=None):
+    """Drive the reference for each policy and dump everything."""
+    n, m = problem.num_vars, problem.num_cons
+    out = dict(
+        n=n, m=m, dt=dt, rho=rho, steps=steps,
+        tau=np.nan if tau is None else tau,
+        x0=np.asarray(x0, float), y0=np.asarray(y0, float),
+        var_lb=problem.var_lb, var_ub=problem.var_ub,
+        policies=np.array(policies),
+    )
+    if store_problem:
+        for k, v in store_problem.items():
+            out["problem/" + k] = v
+    min_margin = np.inf
+    # constant H, J are stored once under problem/ (keeps the fixtures small)
+    constant_derivs = bool(store_problem) and store_problem.get("kind") == "lq"
+    for pol in policies:
+        kw = {}
+        if tau is not None:
+            kw = dict(active_set_type="Explicit", active_set_tau=tau)
+        params = Params(newton_type=NewtonType[pol], **kw)
+        orig = Iterate(problem, params, np.asarray(x0, float), np.asarray(y0, float))
+        method = newton_method(problem, params, orig, dt, rho, tau)
+        ufunc = ImplicitFunc(problem, orig, dt)
+        it = orig
+        for k in range(steps):
+            step = method.step(it)
+            ss = method.step_solver
+            pre = f"{pol}/{k}/"
+            # inputs consumed at this step
+            out[pre + "x"] = it.x
+            out[pre + "y"] = it.y
+            out[pre + "obj_grad"] = it.obj_grad
+            out[pre + "cons"] = it.cons
+            out[pre + "g"] = it.aug_lag_deriv_x(rho)
+            if not constant_derivs:
+                out[pre + "jac_at_x"] = _dense(it.cons_jac)
+                # matrices the solver froze (may stem from the outer iterate)
+                out[pre + "H"] = _dense(ss.hess)
+                out[pre + "J"] = _dense(ss.jac)
+            # outputs
+            mask = np.asarray(step.active_set)
+            out[pre + "mask"] = mask
+            p = ss.func.projection_initial(it, rho, tau)
+            out[pre + "p"] = p
+            min_margin = min(min_margin, _margin(p, ss.func.lb, ss.func.ub))
+            F = ss.func.value_at(it, rho, mask)
+            out[pre + "F"] = F
+            b0, b1, b2 = ss.initial_rhs(it)
+            lamb = 1.0 / dt
+            fact = 1.0 / (1.0 + lamb * rho)
+            act = np.where(mask)[0]
+            rhs = ss.compute_rhs(act, b0, b1, fact * b2)
+            out[pre + "rhs"] = rhs
+            out[pre + "K"] = _dense(ss.deriv)
+            out[pre + "s"] = ss.solver.solve(rhs)
+            Kd = _dense(ss.deriv)
+            out[pre + "n_neg"] = int((np.linalg.eigvalsh(0.5 * (Kd + Kd.T)) < 0).sum()) if Kd.shape[0] else 0
+            out[pre + "dx"] = step.dx
+            out[pre + "dy"] = step.dy
+            out[pre + "xn"] = step.iterate.x
+            out[pre + "yn"] = step.iterate.y
+            out[pre + "diff"] = step.diff
+            out[pre + "res_norm"] = np.linalg.norm(ufunc.value_at(step.iterate, rho))
+            it = step.iterate
+    out["min_mask_margin"] = min_margin
+    assert min_margin > 1e-9, (name, min_margin)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: n={n} m={m} steps={steps} margin={min_margin:.2e}")
+
+
+def qp_store(prob):
+    return dict(kind="lq", Q=prob.hess_dense(), q=prob.q, A=prob.jac_dense(), b=prob.b)
+
+
+def quartic_store(prob):
+    return dict(kind="quartic", Q=prob.Q, q=prob.q, a=prob.a, A=prob.A, B=prob.B, b=prob.b)
+
+
+def linear_solver_cases():
+    """The 5x5 systems of reference tests/pygradflow/test_linear_solver.py:19-83,
+    rebuilt from their definition, with the reference LU solution."""
+    base = np.array(
+        [[2, 1, 0, 0, 0], [1, 4, 1, 0, 1], [0, 1, 3, 2, 0], [0, 0, 2, -1, 0], [0, 1, 0, 0, 2]],
+        dtype=float,
+    )
+    ev = np.linalg.eigvalsh(base)
+    posdef = base - min(2.0 * ev.min(), 0.0) * np.eye(5)
+    negdef = base - max(2.0 * ev.max(), 0.0) * np.eye(5)
+    rhs = np.array([4.0, 17.0, 19.0, 2.0, 12.0])
+    out = dict(rhs=rhs)
+    for nm, mat in (("indef", base), ("posdef", posdef), ("negdef", negdef)):
+        sol = linear_solver(sps.csc_matrix(mat), LinearSolverType.LU, symmetric=True).solve(rhs)
+        solT = linear_solver(sps.csc_matrix(mat), LinearSolverType.LU, symmetric=True).solve(rhs, trans=True)
+        out[nm + "/mat"] = mat
+        out[nm + "/sol"] = sol
+        out[nm + "/sol_trans"] = solT
+        out[nm + "/n_neg"] = int((np.linalg.eigvalsh(mat) < 0).sum())
+    np.savez_compressed(os.path.join(OUT, "linear_solver_5x5.npz"), **out)
+    print("linear_solver_5x5 written")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    from tests.pygradflow.hs71 import HS71  # reference fixtures
+    from tests.pygradflow.rosenbrock import Rosenbrock
+    from tests.pygradflow.tame import Tame
+
+    # reference test_solver.py:191-215 (one-step convergence, dt=10, rho=1)
+    run_case("tame_dt10", Tame(), [0.0, 0.0], [0.0], 10.0, 1.0, 2)
+    # HS71 from its documented start (instances.py:34-42), bounds active
+    run_case("hs71_dt0p25", HS71(), [1.0, 5.0, 5.0, 1.0, 0.0], [0.0, 0.0], 0.25, 1.0, 3)
+    # Rosenbrock, m = 0 (config 1's problem), x0 = (0,0)
+    run_case("rosenbrock_dt0p01", Rosenbrock(), [0.0, 0.0], [], 0.01, 1.0, 3)
+    # all-active edge case of test_newton.py:179-214: K is 0x0
+    rb = Rosenbrock()
+    rb.var_lb = np.array([1.0, 1.0])
+    rb.var_ub = np.array([1.0, np.inf])
+    run_case("rosenbrock_allactive", rb, [0.0, 0.0], [], 1e-12, 1.0, 1)
+
+    # boxed QP n=49 of test_qp.py:29-42 rebuilt from its definition (m = 0)
+    n = 49
+    h = 1 / n
+    e = np.ones(n)
+    H = (1 / h**2) * sps.spdiags([-e, 2 * e, -e], [-1, 0, 1], n, n).toarray()
+    lb = np.linspace(0, -0.01, n + 2)[1:-1].copy()
+    lb[n // 4] = lb[3 * n // 4] = lb[n // 2] = 0.0
+    bq = P.LinearQuadraticProblem(H, e.copy(), np.zeros((0, n)), np.zeros(0), lb, np.inf * e)
+    run_case("boxed_qp49", bq, np.zeros(n), [], 1e-3, 1.0, 4, store_problem=qp_store(bq))
+
+    # random bounded non-convex NLP, SURVEY 8(a) verification case
+    qn = P.quartic_nlp(12, 4, seed=3)
+    x0 = np.clip(np.zeros(12), qn.var_lb, qn.var_ub)
+    run_case("quartic_n12_m4", qn, x0, np.zeros(4), 0.5, 0.7, 4, store_problem=quartic_store(qn))
+    run_case("quartic_n12_m4_tau", qn, x0, np.zeros(4), 0.5, 0.7, 3, tau=0.3,
+             store_problem=quartic_store(qn))
+    qn2 = P.quartic_nlp(40, 12, seed=11)
+    run_case("quartic_n40_m12", qn2, np.zeros(40), np.zeros(12), 0.25, 1.3, 4,
+             store_problem=quartic_store(qn2))
+
+    # size-reduced BASELINE configs 2 / 2b / 3 / 5
+    d2 = P.dense_qp(64, 16, seed=0)
+    run_case("dense_qp_n64_m16", d2, np.zeros(64), np.zeros(16), 1.0, 1.0, 3, store_problem=qp_store(d2))
+    d2b = P.dense_qp(96, 24, seed=1, boxed_frac=0.25)
+    run_case("dense_qp_boxed_n96_m24", d2b, np.zeros(96), np.zeros(24), 1.0, 1.0, 4,
+             store_problem=qp_store(d2b))
+    d2c = P.dense_qp(200, 56, seed=2, boxed_frac=0.4, box=0.05)
+    run_case("dense_qp_boxed_n200_m56", d2c, np.zeros(200), np.zeros(56), 0.5, 2.0, 3,
+             store_problem=qp_store(d2c))
+    o3 = P.sparse_ocp(40, seed=0)
+    run_case("ocp_m40", o3, np.zeros(80), np.zeros(40), 1.0, 1.0, 3, store_problem=qp_store(o3))
+    b5 = P.box_qp(256, seed=0)
+    run_case("box_qp_n256", b5, np.zeros(256), [], 1.0, 1.0, 6, store_problem=qp_store(b5))
+
+    linear_solver_cases()
+
+
+if __name__ == "__main__":
+    main()
