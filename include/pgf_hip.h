@@ -1,0 +1,163 @@
+/*
+ * pgf_hip.h -- C ABI of the MI355X-native semi-smooth Newton / KKT step.
+ *
+ * Drop-in boundary for ONE hot path of chrhansk/pygradflow (v0.5.24): everything
+ * executed inside one NewtonMethod.step(iterate) with the default
+ * StepSolverType.Symmetric.  Plain C: opaque handles,
+ * raw pointers + sizes, int status returns, no callbacks, no exceptions.
+ *
+ * Each entry point cites the reference interface (file:line, relative to the
+ * pygradflow checkout) whose arithmetic it replaces.  INTEGRATION.md shows the
+ * ctypes stub a pygradflow maintainer would add.
+ *
+ * Conventions
+ *   - all floating point is IEEE binary64 (Params.dtype, params.py:275-277);
+ *   - masks are one byte per variable, 0 / 1 (numpy bool_);
+ *   - `loc` says where an input pointer lives: PGF_HOST or PGF_DEVICE;
+ *     outputs are host pointers unless the name says `_dev`;
+ *   - one caller thread per handle; one HIP stream per handle;
+ *   - caller owns every host buffer, the library owns every device buffer.
+ *
+ * Status codes (mapped by the Python shim):
+ *   0 ok | 1 singular / zero pivot -> LinearSolverError
+ *   2 inertia mismatch -> LinearSolverError | 3 invalid argument -> ValueError
+ *   4 called out of order -> RuntimeError | >=100 HIP runtime error -> RuntimeError
+ */
+#ifndef PGF_HIP_H
+#define PGF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGF_OK 0
+#define PGF_SINGULAR 1
+#define PGF_INERTIA 2
+#define PGF_INVALID 3
+#define PGF_NOT_READY 4
+#define PGF_HIP_ERROR 100
+
+#define PGF_HOST 0
+#define PGF_DEVICE 1
+
+/* pgf_qp_step policy bits (NewtonMethod policies, newton.py:35-60, 63-89, 181-215) */
+#define PGF_STEP_RECOMPUTE_MASK 1u  /* Full, ActiveSet: mask from the current point  */
+#define PGF_STEP_REFACTOR 2u        /* Full: assemble + factor every step             */
+#define PGF_STEP_REFACTOR_ON_CHANGE 4u /* ActiveSet: refactor iff the mask changed     */
+
+typedef struct pgf_solver *pgf_handle;
+typedef struct pgf_linsolver *pgf_ls_handle;
+
+/* ---- library ---------------------------------------------------------- */
+int pgf_version(void);
+int pgf_device_count(int *count);
+/* static description of the last error on this handle (never NULL) */
+const char *pgf_last_error(pgf_handle h);
+
+/* ---- step-solver handle: one per (n, m); reusable across outer steps --- */
+/* replaces SymmetricStepSolver.__init__ (step/solver/symmetric_step_solver.py:14-25,
+ * scaled_step_solver.py:16-33) -- allocation only */
+int pgf_create(int n, int m, int device, unsigned flags, pgf_handle *out);
+int pgf_destroy(pgf_handle h);
+
+/* Problem.var_lb / var_ub (problem.py:57-62); +-inf allowed */
+int pgf_set_bounds(pgf_handle h, const double *lb, const double *ub);
+
+/* one outer step: x^, y^, dt, rho.  Pre-scales the bounds lamb*lb, lamb*ub
+ * (ScaledImplicitFunc.__init__, implicit_func.py:211-216); drops mask, K, factor */
+int pgf_set_outer(pgf_handle h, const double *xhat, const double *yhat, double dt, double rho);
+
+/* ScaledStepSolver.update_derivs (scaled_step_solver.py:76-79,
+ * symmetric_step_solver.py:41-43): H = lag_hess(x, y) (no rho J'J), J = cons_jac.
+ * Dense row-major; only the lower triangle of H is read.  PGF_HOST pointers are
+ * copied to HBM; PGF_DEVICE pointers are adopted (caller keeps them alive).
+ * Invalidates K and its factor. */
+int pgf_set_derivs_dense(pgf_handle h, const double *H, int64_t ldh, const double *J,
+                         int64_t ldj, int loc);
+
+/* StepFunc.compute_active_set (implicit_func.py:72-74) =
+ * projection_initial (:233-246, tau = NaN means None) + compute_active_set_box (:21-44).
+ * x, g: current point and g = aug_lag_deriv_x(rho) (iterate.py:91-94). mask_out[n]. */
+int pgf_active_set(pgf_handle h, const double *x, const double *g, double tau,
+                   uint8_t *mask_out);
+
+/* ScaledStepSolver.update_active_set (scaled_step_solver.py:81-83) */
+int pgf_set_active_set(pgf_handle h, const uint8_t *mask);
+
+/* SymmetricStepSolver._compute_deriv (:49-77) + linear_solver()/LUSolver.__init__
+ * (:129-133, linear_solver/lu_solver.py:9-17): gather-assemble the reduced KKT matrix
+ * for the current mask in HBM and factor it (LDL^T, K symmetric quasi-definite).
+ * n_neg = number of negative pivots = LinearSolver.num_neg_eigvals().
+ * Returns PGF_SINGULAR on a zero / non-finite pivot. */
+int pgf_factor(pgf_handle h, int *n_neg);
+
+/* ScaledStepSolver.solve (scaled_step_solver.py:85-107) for the current mask/factor:
+ * residual (implicit_func.py:219-231), rhs split (:38-60), reduced rhs
+ * (symmetric_step_solver.py:79-94), solve (:135-158), scatter (:115-121),
+ * dy (:104), StepResult clipping and diff (step_solver.py:16-63).
+ * c may be NULL when m == 0.  Factors first if needed (status as pgf_factor).
+ * inertia_check != 0 and n_neg != m  ->  PGF_INERTIA (:146-153). */
+int pgf_newton_solve(pgf_handle h, const double *x, const double *y, const double *g,
+                     const double *c, int inertia_check, double *dx, double *dy,
+                     double *xn, double *yn, double *diff);
+
+/* ScaledImplicitFunc.value_at (implicit_func.py:219-231); mask NULL = recompute at p */
+int pgf_residual(pgf_handle h, const double *x, const double *y, const double *g,
+                 const double *c, const uint8_t *mask, double *F_out);
+
+/* LinearSolver.solve(rhs, trans) (linear_solver/linear_solver.py:23-25) against the
+ * current reduced KKT factor; rhs/sol have |I| + m entries */
+int pgf_linear_solve(pgf_handle h, const double *rhs, int trans, double *sol);
+
+/* size of the reduced system of the current mask: |I|, |I| + m */
+int pgf_reduced_dims(pgf_handle h, int *n_inactive, int *n_reduced);
+/* copy the assembled (pre-factor) lower triangle of K to host, row-major N x N
+ * (debug / parity; re-assembles, does not disturb the factor) */
+int pgf_get_kkt(pgf_handle h, double *K_out, int64_t ldk);
+
+/* ---- device-resident linear-quadratic mode (bench, batched mode) -------- */
+/* f = 1/2 x'Qx + q'x, c = Ax - b: H = Q and J = A stay in HBM; g and c are
+ * evaluated on device (SURVEY.md 8d "Problem data device-resident"). */
+int pgf_qp_set_problem(pgf_handle h, const double *Q, int64_t ldq, const double *q,
+                       const double *A, int64_t lda, const double *b, int loc);
+int pgf_qp_set_point(pgf_handle h, const double *x, const double *y);
+int pgf_qp_get_point(pgf_handle h, double *x, double *y);
+int pgf_qp_get_mask(pgf_handle h, uint8_t *mask);
+/* mask <- compute_active_set at the device point (SimplifiedNewtonMethod.__init__,
+ * newton.py:52-56: call once at (x^, y^)); *changed = 1 if the stored mask was replaced */
+int pgf_qp_update_active_set(pgf_handle h, double tau, int *changed);
+/* One NewtonMethod.step on the device-resident point (policy bits above; tau NaN = None).
+ * (x, y) <- (xn, yn).  n_neg / diff may be NULL.  One host sync at the end
+ * (plus one to read |I| when the mask is recomputed). */
+int pgf_qp_step(pgf_handle h, unsigned policy, double tau, int inertia_check, int *n_neg,
+                double *diff);
+/* enqueue-only variant for timing loops: no host sync, status checked by pgf_qp_sync */
+int pgf_qp_step_async(pgf_handle h, unsigned policy, double tau);
+int pgf_qp_sync(pgf_handle h, int *n_neg, double *diff);
+/* ||F(z)||_2 of the UNSCALED residual (ImplicitFunc.value_at, implicit_func.py:150-161)
+ * at the device point; host result, and optionally a device slot (RCCL all-gather input) */
+int pgf_qp_residual_norm(pgf_handle h, double *norm_out, double *norm_out_dev);
+/* HIP stream of the handle (void* = hipStream_t) for event timing by the caller */
+int pgf_stream(pgf_handle h, void **stream_out);
+/* device time (ms) spent in the factor's trailing-update launches since the last call,
+ * their count and algorithmic flops -- measured with HIP events on the handle's stream */
+int pgf_profile_enable(pgf_handle h, int on);
+int pgf_profile_read(pgf_handle h, double *update_ms, int64_t *update_launches,
+                     double *update_flops, double *factor_ms);
+
+/* ---- stand-alone dense linear solver (LinearSolver ABC) ------------------ */
+/* LinearSolver.__init__ factorises in the constructor
+ * (linear_solver/linear_solver.py:18-21, lu_solver.py:9-17).  A: dense row-major N x N.
+ * symmetric != 0: LDL^T on the lower triangle.  PGF_SINGULAR on failure. */
+int pgf_ls_create_dense(int N, const double *A, int64_t lda, int symmetric, int device,
+                        pgf_ls_handle *out);
+int pgf_ls_solve(pgf_ls_handle ls, const double *rhs, int trans, double *sol);
+int pgf_ls_num_neg(pgf_ls_handle ls, int *out);
+int pgf_ls_destroy(pgf_ls_handle ls);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGF_HIP_H */

@@ -1,0 +1,755 @@
+// C ABI of libpgf_hip.so (include/pgf_hip.h): handle management and the per-step
+// orchestration of the kernels in pgf_kernels.hip / pgf_ldlt.hip.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <utility>
+
+#include "../../include/pgf_hip.h"
+#include "pgf_internal.h"
+#include "pgf_kernels.h"
+
+#define PGF_GEMVT_PARTS 32
+
+struct pgf_solver {
+  int n = 0, m = 0, device = 0;
+  hipStream_t stream = nullptr;
+  std::string err = "";
+  // host-known state
+  double dt = 0, lamb = 0, rho = 0, fact = 0, delta = 0;
+  bool bounds_set = false, outer_set = false, derivs_set = false, mask_set = false;
+  bool qp_mode = false, point_set = false, eval_fresh = false;
+  int nI = 0, nA = 0, N = 0;
+  // device data
+  double *H = nullptr, *J = nullptr;
+  int64_t ldh = 0, ldj = 0;
+  bool ownH = false, ownJ = false;
+  double *Hown = nullptr, *Jown = nullptr;  // library-owned storage (reused across uploads)
+  double *lb = nullptr, *ub = nullptr, *slb = nullptr, *sub = nullptr;
+  double *xhat = nullptr, *yhat = nullptr;
+  double *x = nullptr, *y = nullptr, *xn = nullptr, *yn = nullptr;
+  double *g = nullptr, *c = nullptr, *F = nullptr, *b0full = nullptr;
+  double *rhs = nullptr, *sol = nullptr, *dx = nullptr, *dy = nullptr;
+  double *q = nullptr, *b = nullptr, *w = nullptr, *tmpn = nullptr, *partial = nullptr;
+  double *red = nullptr, *scal = nullptr;  // scal[0] diff, scal[1] residual norm
+  uint8_t *mask = nullptr, *mask_new = nullptr;
+  int *idxI = nullptr, *idxA = nullptr, *pos = nullptr, *counts = nullptr;
+  // pinned host mirrors
+  int *h_counts = nullptr;
+  double *h_scal = nullptr;
+  DenseLdlt fac;
+  PgfProfile prof;
+  bool step_pending = false;
+};
+
+struct pgf_linsolver {
+  int N = 0, device = 0;
+  hipStream_t stream = nullptr;
+  DenseLdlt fac;
+  double *rhs = nullptr, *sol = nullptr;
+};
+
+static const char *k_no_handle = "null handle";
+
+static int fail(pgf_handle h, int code, const char *msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+static int hip_fail(pgf_handle h, hipError_t e, const char *where) {
+  if (h) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", where, hipGetErrorString(e));
+    h->err = buf;
+  }
+  return PGF_HIP_ERROR + (int)e;
+}
+
+#define HIPCHK(h, call)                                  \
+  do {                                                   \
+    hipError_t e__ = (call);                             \
+    if (e__ != hipSuccess) return hip_fail(h, e__, #call); \
+  } while (0)
+
+template <typename T>
+static hipError_t dalloc(T **p, size_t count) {
+  return hipMalloc((void **)p, (count ? count : 1) * sizeof(T));
+}
+
+extern "C" {
+
+int pgf_version(void) { return 1; }
+
+int pgf_device_count(int *count) {
+  if (!count) return PGF_INVALID;
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) {
+    *count = 0;
+    return PGF_HIP_ERROR + (int)e;
+  }
+  return PGF_OK;
+}
+
+const char *pgf_last_error(pgf_handle h) { return h ? h->err.c_str() : k_no_handle; }
+
+int pgf_create(int n, int m, int device, unsigned flags, pgf_handle *out) {
+  (void)flags;
+  if (!out || n < 0 || m < 0 || (int64_t)n + m > 60000) return PGF_INVALID;
+  pgf_handle h = new (std::nothrow) pgf_solver();
+  if (!h) return PGF_INVALID;
+  h->n = n;
+  h->m = m;
+  h->device = device;
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) {
+    delete h;
+    return PGF_HIP_ERROR + (int)e;
+  }
+#define A_(ptr, cnt)                                        \
+  if ((e = dalloc(&h->ptr, (size_t)(cnt))) != hipSuccess) { \
+    pgf_destroy(h);                                         \
+    return PGF_HIP_ERROR + (int)e;                          \
+  }
+  if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) {
+    delete h;
+    return PGF_HIP_ERROR + (int)e;
+  }
+  const int N = n + m;
+  A_(lb, n) A_(ub, n) A_(slb, n) A_(sub, n) A_(xhat, n) A_(yhat, m);
+  A_(x, n) A_(y, m) A_(xn, n) A_(yn, m) A_(g, n) A_(c, m) A_(F, N) A_(b0full, n);
+  A_(rhs, N + 1) A_(sol, N + 1) A_(dx, n) A_(dy, m);
+  A_(q, n) A_(b, m) A_(w, m) A_(tmpn, n) A_(partial, (size_t)PGF_GEMVT_PARTS * (n ? n : 1));
+  A_(red, (N + 255) / 256 + 1) A_(scal, 4);
+  A_(mask, n) A_(mask_new, n) A_(idxI, n) A_(idxA, n) A_(pos, n) A_(counts, 4);
+#undef A_
+  if ((e = hipHostMalloc((void **)&h->h_counts, 4 * sizeof(int))) != hipSuccess ||
+      (e = hipHostMalloc((void **)&h->h_scal, 4 * sizeof(double))) != hipSuccess) {
+    pgf_destroy(h);
+    return PGF_HIP_ERROR + (int)e;
+  }
+  if ((e = ldlt_alloc(h->fac, N, h->stream)) != hipSuccess) {
+    pgf_destroy(h);
+    return PGF_HIP_ERROR + (int)e;
+  }
+  h->fac.prof = &h->prof;
+  *out = h;
+  return PGF_OK;
+}
+
+int pgf_destroy(pgf_handle h) {
+  if (!h) return PGF_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  void *ptrs[] = {h->Hown, h->Jown, h->lb,  h->ub,   h->slb,  h->sub,      h->xhat, h->yhat,
+                  h->x,    h->y,    h->xn,  h->yn,   h->g,    h->c,        h->F,    h->b0full,
+                  h->rhs,  h->sol,  h->dx,  h->dy,   h->q,    h->b,        h->w,    h->tmpn,
+                  h->partial, h->red, h->scal, h->mask, h->mask_new, h->idxI, h->idxA, h->pos,
+                  h->counts};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  if (h->h_counts) (void)hipHostFree(h->h_counts);
+  if (h->h_scal) (void)hipHostFree(h->h_scal);
+  ldlt_free(h->fac);
+  for (hipEvent_t e : h->prof.pool) (void)hipEventDestroy(e);
+  for (auto &sp : h->prof.update_spans) {
+    (void)hipEventDestroy(sp.first);
+    (void)hipEventDestroy(sp.second);
+  }
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return PGF_OK;
+}
+
+static int up(pgf_handle h, void *dst, const void *src, size_t bytes) {
+  if (!bytes) return PGF_OK;
+  HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+  return PGF_OK;
+}
+
+static int down(pgf_handle h, void *dst, const void *src, size_t bytes) {
+  if (!bytes) return PGF_OK;
+  HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+  return PGF_OK;
+}
+
+static void invalidate_factor(pgf_handle h) { h->fac.factored = false; }
+
+int pgf_set_bounds(pgf_handle h, const double *lb, const double *ub) {
+  if (!h) return PGF_INVALID;
+  if (h->n && (!lb || !ub)) return fail(h, PGF_INVALID, "null bounds");
+  (void)hipSetDevice(h->device);
+  int rc;
+  if ((rc = up(h, h->lb, lb, h->n * sizeof(double)))) return rc;
+  if ((rc = up(h, h->ub, ub, h->n * sizeof(double)))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->bounds_set = true;
+  if (h->outer_set) launch_scale_bounds(h->stream, h->n, h->lamb, h->lb, h->ub, h->slb, h->sub);
+  return PGF_OK;
+}
+
+int pgf_set_outer(pgf_handle h, const double *xhat, const double *yhat, double dt, double rho) {
+  if (!h) return PGF_INVALID;
+  if (!(dt > 0.0) || !(rho > 0.0)) return fail(h, PGF_INVALID, "dt and rho must be positive");
+  if (!h->bounds_set) return fail(h, PGF_NOT_READY, "pgf_set_bounds first");
+  if ((h->n && !xhat) || (h->m && !yhat)) return fail(h, PGF_INVALID, "null outer iterate");
+  (void)hipSetDevice(h->device);
+  int rc;
+  if ((rc = up(h, h->xhat, xhat, h->n * sizeof(double)))) return rc;
+  if ((rc = up(h, h->yhat, yhat, h->m * sizeof(double)))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->dt = dt;
+  h->lamb = 1.0 / dt;
+  h->rho = rho;
+  h->fact = 1.0 / (1.0 + h->lamb * rho);
+  h->delta = h->lamb / (1.0 + h->lamb * rho);
+  launch_scale_bounds(h->stream, h->n, h->lamb, h->lb, h->ub, h->slb, h->sub);
+  h->outer_set = true;
+  h->mask_set = false;
+  invalidate_factor(h);
+  return PGF_OK;
+}
+
+static int set_matrix(pgf_handle h, const double *src, int64_t ld, int rows, int cols, int loc,
+                      double **own, double **cur, int64_t *curld, bool *owned) {
+  if (rows == 0 || cols == 0) {
+    *cur = nullptr;
+    *curld = cols;
+    return PGF_OK;
+  }
+  if (!src || ld < cols) return fail(h, PGF_INVALID, "bad matrix pointer / leading dimension");
+  if (loc == PGF_DEVICE) {
+    *cur = const_cast<double *>(src);
+    *curld = ld;
+    *owned = false;
+    return PGF_OK;
+  }
+  if (!*own) HIPCHK(h, dalloc(own, (size_t)rows * cols));
+  HIPCHK(h, hipMemcpy2DAsync(*own, (size_t)cols * sizeof(double), src, (size_t)ld * sizeof(double),
+                             (size_t)cols * sizeof(double), rows, hipMemcpyHostToDevice,
+                             h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  *cur = *own;
+  *curld = cols;
+  *owned = true;
+  return PGF_OK;
+}
+
+int pgf_set_derivs_dense(pgf_handle h, const double *H, int64_t ldh, const double *J, int64_t ldj,
+                         int loc) {
+  if (!h) return PGF_INVALID;
+  (void)hipSetDevice(h->device);
+  int rc;
+  if ((rc = set_matrix(h, H, ldh, h->n, h->n, loc, &h->Hown, &h->H, &h->ldh, &h->ownH))) return rc;
+  if ((rc = set_matrix(h, J, ldj, h->m, h->n, loc, &h->Jown, &h->J, &h->ldj, &h->ownJ))) return rc;
+  h->derivs_set = true;
+  invalidate_factor(h);
+  return PGF_OK;
+}
+
+static void tau_factors(pgf_handle h, double tau, int *use_tau, double *f_x, double *f_x0,
+                        double *f_d) {
+  // implicit_func.py:237-244
+  *use_tau = std::isnan(tau) ? 0 : 1;
+  const double lamb = 1.0 / h->dt;
+  *f_x = *use_tau ? lamb * (1 - tau * lamb) : 0.0;
+  *f_x0 = *use_tau ? tau * lamb * lamb : 0.0;
+  *f_d = *use_tau ? tau * lamb : 0.0;
+}
+
+int pgf_active_set(pgf_handle h, const double *x, const double *g, double tau, uint8_t *mask_out) {
+  if (!h) return PGF_INVALID;
+  if (!h->outer_set) return fail(h, PGF_NOT_READY, "pgf_set_outer first");
+  if (h->n && (!x || !g || !mask_out)) return fail(h, PGF_INVALID, "null argument");
+  (void)hipSetDevice(h->device);
+  int rc;
+  if ((rc = up(h, h->tmpn, x, h->n * sizeof(double)))) return rc;
+  if ((rc = up(h, h->g, g, h->n * sizeof(double)))) return rc;
+  int use_tau;
+  double f_x, f_x0, f_d;
+  tau_factors(h, tau, &use_tau, &f_x, &f_x0, &f_d);
+  launch_active_set(h->stream, h->n, use_tau, h->lamb, f_x, f_x0, f_d, h->xhat, h->tmpn, h->g,
+                    h->slb, h->sub, h->mask_new);
+  if ((rc = down(h, mask_out, h->mask_new, h->n))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->eval_fresh = false;
+  return PGF_OK;
+}
+
+// compaction of h->mask -> index lists + counts (one host sync)
+static int refresh_index_sets(pgf_handle h) {
+  launch_compact(h->stream, h->n, h->mask, h->idxI, h->idxA, h->pos, h->counts);
+  int rc;
+  if ((rc = down(h, h->h_counts, h->counts, 2 * sizeof(int)))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->nI = h->h_counts[0];
+  h->nA = h->h_counts[1];
+  h->N = h->nI + h->m;
+  h->mask_set = true;
+  invalidate_factor(h);
+  return PGF_OK;
+}
+
+int pgf_set_active_set(pgf_handle h, const uint8_t *mask) {
+  if (!h) return PGF_INVALID;
+  if (h->n && !mask) return fail(h, PGF_INVALID, "null mask");
+  (void)hipSetDevice(h->device);
+  int rc;
+  if ((rc = up(h, h->mask, mask, h->n))) return rc;
+  return refresh_index_sets(h);
+}
+
+int pgf_reduced_dims(pgf_handle h, int *n_inactive, int *n_reduced) {
+  if (!h) return PGF_INVALID;
+  if (!h->mask_set) return fail(h, PGF_NOT_READY, "no active set");
+  if (n_inactive) *n_inactive = h->nI;
+  if (n_reduced) *n_reduced = h->N;
+  return PGF_OK;
+}
+
+static int check_ready(pgf_handle h) {
+  if (!h->outer_set) return fail(h, PGF_NOT_READY, "pgf_set_outer first");
+  if (!h->derivs_set) return fail(h, PGF_NOT_READY, "pgf_set_derivs_* first");
+  if (!h->mask_set) return fail(h, PGF_NOT_READY, "pgf_set_active_set first");
+  return PGF_OK;
+}
+
+static void assemble(pgf_handle h, double *K, int64_t ldk) {
+  launch_assemble_kkt(h->stream, K, ldk, h->H, h->ldh, h->J, h->ldj, h->idxI, h->nI, h->m, h->lamb,
+                      h->delta);
+}
+
+// enqueue assemble + factor; with_rhs: carry h->rhs through the elimination in row N
+static int factor_async(pgf_handle h, bool with_rhs) {
+  assemble(h, h->fac.K, h->fac.ldk);
+  if (with_rhs && h->N > 0)
+    launch_copy(h->stream, h->fac.K + (int64_t)h->N * h->fac.ldk, h->rhs, h->N);
+  HIPCHK(h, ldlt_factor_async(h->fac, h->N, h->N + (with_rhs ? 1 : 0)));
+  return PGF_OK;
+}
+
+static int factor_finish(pgf_handle h) {
+  hipError_t e;
+  const int st = ldlt_finish(h->fac, &e);
+  if (st < 0) return hip_fail(h, e, "factor");
+  if (st == 1) return fail(h, PGF_SINGULAR, "zero or non-finite pivot in LDL^T of the KKT matrix");
+  return PGF_OK;
+}
+
+int pgf_factor(pgf_handle h, int *n_neg) {
+  if (!h) return PGF_INVALID;
+  int rc;
+  if ((rc = check_ready(h))) return rc;
+  (void)hipSetDevice(h->device);
+  if ((rc = factor_async(h, false))) return rc;
+  if ((rc = factor_finish(h))) return rc;
+  if (n_neg) *n_neg = h->fac.n_neg;
+  return PGF_OK;
+}
+
+// residual + reduced rhs for the point in (h->x, h->y, h->g, h->c), then solve and update.
+// Everything is enqueued; returns without syncing.  factored_out tells whether a factor
+// was enqueued (its flags then need checking at the sync).
+static int newton_core_async(pgf_handle h, bool *did_factor) {
+  hipStream_t s = h->stream;
+  launch_residual(s, h->n, h->m, h->lamb, h->dt, h->xhat, h->yhat, h->x, h->y, h->g, h->c, h->slb,
+                  h->sub, h->mask, h->F, h->b0full);
+  launch_reduced_rhs(s, h->n, h->m, h->nI, h->nA, h->fact, h->F, h->idxI, h->H, h->ldh, h->J,
+                     h->ldj, h->b0full, h->rhs);
+  *did_factor = false;
+  if (!h->fac.factored) {
+    int rc;
+    if ((rc = factor_async(h, true))) return rc;
+    *did_factor = true;
+    HIPCHK(h, ldlt_backsolve_async(h->fac, h->fac.K + (int64_t)h->N * h->fac.ldk, h->sol));
+  } else {
+    HIPCHK(h, ldlt_solve_async(h->fac, h->rhs, h->sol));
+  }
+  launch_step_update(s, h->n, h->m, h->nI, h->fact, h->rho, h->x, h->y, h->lb, h->ub, h->mask,
+                     h->pos, h->b0full, h->F, h->sol, h->dx, h->dy, h->xn, h->yn, h->red,
+                     h->scal);
+  return PGF_OK;
+}
+
+int pgf_newton_solve(pgf_handle h, const double *x, const double *y, const double *g,
+                     const double *c, int inertia_check, double *dx, double *dy, double *xn,
+                     double *yn, double *diff) {
+  if (!h) return PGF_INVALID;
+  int rc;
+  if ((rc = check_ready(h))) return rc;
+  if ((h->n && (!x || !g)) || (h->m && (!y || !c))) return fail(h, PGF_INVALID, "null argument");
+  (void)hipSetDevice(h->device);
+  if ((rc = up(h, h->x, x, h->n * sizeof(double)))) return rc;
+  if ((rc = up(h, h->y, y, h->m * sizeof(double)))) return rc;
+  if ((rc = up(h, h->g, g, h->n * sizeof(double)))) return rc;
+  if ((rc = up(h, h->c, c, h->m * sizeof(double)))) return rc;
+  h->eval_fresh = false;
+  bool did_factor;
+  if ((rc = newton_core_async(h, &did_factor))) return rc;
+  if (did_factor) {
+    if ((rc = factor_finish(h))) return rc;
+  }
+  if (inertia_check && h->fac.n_neg != h->m) return fail(h, PGF_INERTIA, "Invalid matrix inertia");
+  if (dx && (rc = down(h, dx, h->dx, h->n * sizeof(double)))) return rc;
+  if (dy && (rc = down(h, dy, h->dy, h->m * sizeof(double)))) return rc;
+  if (xn && (rc = down(h, xn, h->xn, h->n * sizeof(double)))) return rc;
+  if (yn && (rc = down(h, yn, h->yn, h->m * sizeof(double)))) return rc;
+  if ((rc = down(h, h->h_scal, h->scal, sizeof(double)))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (diff) *diff = h->h_scal[0];
+  return PGF_OK;
+}
+
+int pgf_residual(pgf_handle h, const double *x, const double *y, const double *g, const double *c,
+                 const uint8_t *mask, double *F_out) {
+  if (!h) return PGF_INVALID;
+  if (!h->outer_set) return fail(h, PGF_NOT_READY, "pgf_set_outer first");
+  if ((h->n && (!x || !g)) || (h->m && (!y || !c)) || !F_out)
+    return fail(h, PGF_INVALID, "null argument");
+  (void)hipSetDevice(h->device);
+  int rc;
+  // scratch: xn / yn / tmpn / w hold the point so the solver state is untouched
+  if ((rc = up(h, h->xn, x, h->n * sizeof(double)))) return rc;
+  if ((rc = up(h, h->yn, y, h->m * sizeof(double)))) return rc;
+  if ((rc = up(h, h->tmpn, g, h->n * sizeof(double)))) return rc;
+  if ((rc = up(h, h->w, c, h->m * sizeof(double)))) return rc;
+  if (mask) {
+    if ((rc = up(h, h->mask_new, mask, h->n))) return rc;
+  } else {
+    launch_active_set(h->stream, h->n, 0, h->lamb, 0, 0, 0, h->xhat, h->xn, h->tmpn, h->slb,
+                      h->sub, h->mask_new);
+  }
+  launch_residual(h->stream, h->n, h->m, h->lamb, h->dt, h->xhat, h->yhat, h->xn, h->yn, h->tmpn,
+                  h->w, h->slb, h->sub, h->mask_new, h->sol, nullptr);
+  if ((rc = down(h, F_out, h->sol, (size_t)(h->n + h->m) * sizeof(double)))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return PGF_OK;
+}
+
+int pgf_linear_solve(pgf_handle h, const double *rhs, int trans, double *sol) {
+  (void)trans;  // K is symmetric
+  if (!h) return PGF_INVALID;
+  int rc;
+  if ((rc = check_ready(h))) return rc;
+  if (h->N && (!rhs || !sol)) return fail(h, PGF_INVALID, "null argument");
+  (void)hipSetDevice(h->device);
+  if (!h->fac.factored) {
+    if ((rc = factor_async(h, false))) return rc;
+    if ((rc = factor_finish(h))) return rc;
+  }
+  if ((rc = up(h, h->rhs, rhs, h->N * sizeof(double)))) return rc;
+  HIPCHK(h, ldlt_solve_async(h->fac, h->rhs, h->sol));
+  if ((rc = down(h, sol, h->sol, h->N * sizeof(double)))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return PGF_OK;
+}
+
+int pgf_get_kkt(pgf_handle h, double *K_out, int64_t ldk_out) {
+  if (!h) return PGF_INVALID;
+  int rc;
+  if ((rc = check_ready(h))) return rc;
+  const int N = h->N;
+  if (N == 0) return PGF_OK;
+  if (!K_out || ldk_out < N) return fail(h, PGF_INVALID, "bad output matrix");
+  (void)hipSetDevice(h->device);
+  double *tmp = nullptr;
+  HIPCHK(h, dalloc(&tmp, (size_t)N * N));
+  HIPCHK(h, hipMemsetAsync(tmp, 0, (size_t)N * N * sizeof(double), h->stream));
+  assemble(h, tmp, N);
+  hipError_t e = hipMemcpy2DAsync(K_out, (size_t)ldk_out * sizeof(double), tmp,
+                                  (size_t)N * sizeof(double), (size_t)N * sizeof(double), N,
+                                  hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) return hip_fail(h, e, "pgf_get_kkt");
+  return PGF_OK;
+}
+
+// ---------------------------------------------------------------- device-resident LQ mode
+int pgf_qp_set_problem(pgf_handle h, const double *Q, int64_t ldq, const double *q,
+                       const double *A, int64_t lda, const double *b, int loc) {
+  if (!h) return PGF_INVALID;
+  if ((h->n && !q) || (h->m && !b)) return fail(h, PGF_INVALID, "null argument");
+  int rc;
+  if ((rc = pgf_set_derivs_dense(h, Q, ldq, A, lda, loc))) return rc;
+  if (loc == PGF_DEVICE) {
+    HIPCHK(h, hipMemcpyAsync(h->q, q, h->n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    if (h->m)
+      HIPCHK(h, hipMemcpyAsync(h->b, b, h->m * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  } else {
+    if ((rc = up(h, h->q, q, h->n * sizeof(double)))) return rc;
+    if ((rc = up(h, h->b, b, h->m * sizeof(double)))) return rc;
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->qp_mode = true;
+  return PGF_OK;
+}
+
+int pgf_qp_set_point(pgf_handle h, const double *x, const double *y) {
+  if (!h) return PGF_INVALID;
+  if ((h->n && !x) || (h->m && !y)) return fail(h, PGF_INVALID, "null argument");
+  (void)hipSetDevice(h->device);
+  int rc;
+  if ((rc = up(h, h->x, x, h->n * sizeof(double)))) return rc;
+  if ((rc = up(h, h->y, y, h->m * sizeof(double)))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->point_set = true;
+  h->eval_fresh = false;
+  return PGF_OK;
+}
+
+int pgf_qp_get_point(pgf_handle h, double *x, double *y) {
+  if (!h) return PGF_INVALID;
+  if (!h->point_set) return fail(h, PGF_NOT_READY, "pgf_qp_set_point first");
+  (void)hipSetDevice(h->device);
+  int rc;
+  if (x && (rc = down(h, x, h->x, h->n * sizeof(double)))) return rc;
+  if (y && (rc = down(h, y, h->y, h->m * sizeof(double)))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return PGF_OK;
+}
+
+int pgf_qp_get_mask(pgf_handle h, uint8_t *mask) {
+  if (!h || !mask) return PGF_INVALID;
+  if (!h->mask_set) return fail(h, PGF_NOT_READY, "no active set");
+  (void)hipSetDevice(h->device);
+  int rc;
+  if ((rc = down(h, mask, h->mask, h->n))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return PGF_OK;
+}
+
+// c = A x - b ; w = rho c + y ; g = Q x + (q + A' w)   at the device point
+static void qp_eval(pgf_handle h) {
+  if (h->eval_fresh) return;
+  hipStream_t s = h->stream;
+  launch_gemv_rows(s, h->m, h->n, h->J, h->ldj, h->x, h->b, -1.0, h->c);
+  launch_mult_vec(s, h->m, h->rho, h->c, h->y, h->w);
+  launch_gemvT(s, h->m, h->n, h->J, h->ldj, h->w, h->q, h->partial, PGF_GEMVT_PARTS, h->tmpn);
+  launch_gemv_rows(s, h->n, h->n, h->H, h->ldh, h->x, h->tmpn, 1.0, h->g);
+  h->eval_fresh = true;
+}
+
+static int qp_ready(pgf_handle h) {
+  if (!h->qp_mode) return fail(h, PGF_NOT_READY, "pgf_qp_set_problem first");
+  if (!h->outer_set) return fail(h, PGF_NOT_READY, "pgf_set_outer first");
+  if (!h->point_set) return fail(h, PGF_NOT_READY, "pgf_qp_set_point first");
+  return PGF_OK;
+}
+
+// mask at the device point -> mask_new; adopt it if it differs (or none yet).
+static int qp_refresh_mask(pgf_handle h, double tau, bool force, int *changed_out) {
+  int use_tau;
+  double f_x, f_x0, f_d;
+  tau_factors(h, tau, &use_tau, &f_x, &f_x0, &f_d);
+  hipStream_t s = h->stream;
+  launch_active_set(s, h->n, use_tau, h->lamb, f_x, f_x0, f_d, h->xhat, h->x, h->g, h->slb, h->sub,
+                    h->mask_new);
+  int changed = 1;
+  if (h->mask_set && !force) {
+    HIPCHK(h, hipMemsetAsync(h->counts + 2, 0, sizeof(int), s));
+    launch_mask_diff(s, h->n, h->mask, h->mask_new, h->counts + 2);
+    int rc;
+    if ((rc = down(h, h->h_counts + 2, h->counts + 2, sizeof(int)))) return rc;
+    HIPCHK(h, hipStreamSynchronize(s));
+    changed = h->h_counts[2] != 0;
+  }
+  if (changed_out) *changed_out = changed;
+  if (changed) {
+    launch_copy_u8(s, h->mask, h->mask_new, h->n);
+    return refresh_index_sets(h);
+  }
+  return PGF_OK;
+}
+
+int pgf_qp_update_active_set(pgf_handle h, double tau, int *changed) {
+  if (!h) return PGF_INVALID;
+  int rc;
+  if ((rc = qp_ready(h))) return rc;
+  (void)hipSetDevice(h->device);
+  qp_eval(h);
+  return qp_refresh_mask(h, tau, false, changed);
+}
+
+int pgf_qp_step_async(pgf_handle h, unsigned policy, double tau) {
+  if (!h) return PGF_INVALID;
+  int rc;
+  if ((rc = qp_ready(h))) return rc;
+  if (h->step_pending) return fail(h, PGF_NOT_READY, "pgf_qp_sync the previous step first");
+  (void)hipSetDevice(h->device);
+  qp_eval(h);
+  if (policy & PGF_STEP_RECOMPUTE_MASK) {
+    // Full (newton.py:83-89): the mask is always re-set, which drops the factor;
+    // ActiveSet (:203-215): only when it differs elementwise.
+    const bool force = (policy & PGF_STEP_REFACTOR) != 0;
+    if ((rc = qp_refresh_mask(h, tau, force, nullptr))) return rc;
+  }
+  if (!h->mask_set) return fail(h, PGF_NOT_READY, "no active set: pgf_qp_update_active_set first");
+  if (policy & PGF_STEP_REFACTOR) invalidate_factor(h);
+  bool did_factor;
+  if ((rc = newton_core_async(h, &did_factor))) return rc;
+  // (x, y) <- (xn, yn)
+  std::swap(h->x, h->xn);
+  std::swap(h->y, h->yn);
+  h->eval_fresh = false;
+  if ((rc = down(h, h->h_scal, h->scal, sizeof(double)))) return rc;
+  h->step_pending = true;
+  return PGF_OK;
+}
+
+int pgf_qp_sync(pgf_handle h, int *n_neg, double *diff) {
+  if (!h) return PGF_INVALID;
+  if (!h->step_pending) return fail(h, PGF_NOT_READY, "no step pending");
+  h->step_pending = false;
+  (void)hipSetDevice(h->device);
+  hipError_t e;
+  const int st = ldlt_finish(h->fac, &e);  // flags are only rewritten by a factor launch
+  if (st < 0) return hip_fail(h, e, "step");
+  if (st == 1) return fail(h, PGF_SINGULAR, "zero or non-finite pivot in LDL^T of the KKT matrix");
+  if (n_neg) *n_neg = h->fac.n_neg;
+  if (diff) *diff = h->h_scal[0];
+  return PGF_OK;
+}
+
+int pgf_qp_step(pgf_handle h, unsigned policy, double tau, int inertia_check, int *n_neg,
+                double *diff) {
+  int rc;
+  if ((rc = pgf_qp_step_async(h, policy, tau))) return rc;
+  if ((rc = pgf_qp_sync(h, n_neg, diff))) return rc;
+  if (inertia_check && h->fac.n_neg != h->m) return fail(h, PGF_INERTIA, "Invalid matrix inertia");
+  return PGF_OK;
+}
+
+int pgf_qp_residual_norm(pgf_handle h, double *norm_out, double *norm_out_dev) {
+  if (!h) return PGF_INVALID;
+  int rc;
+  if ((rc = qp_ready(h))) return rc;
+  (void)hipSetDevice(h->device);
+  qp_eval(h);
+  launch_unscaled_res_norm(h->stream, h->n, h->m, h->dt, h->xhat, h->yhat, h->x, h->y, h->g, h->c,
+                           h->lb, h->ub, h->red, h->scal + 1);
+  if (norm_out_dev)
+    HIPCHK(h, hipMemcpyAsync(norm_out_dev, h->scal + 1, sizeof(double), hipMemcpyDeviceToDevice,
+                             h->stream));
+  if ((rc = down(h, h->h_scal + 1, h->scal + 1, sizeof(double)))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (norm_out) *norm_out = h->h_scal[1];
+  return PGF_OK;
+}
+
+int pgf_stream(pgf_handle h, void **stream_out) {
+  if (!h || !stream_out) return PGF_INVALID;
+  *stream_out = (void *)h->stream;
+  return PGF_OK;
+}
+
+int pgf_profile_enable(pgf_handle h, int on) {
+  if (!h) return PGF_INVALID;
+  h->prof.enabled = on != 0;
+  return PGF_OK;
+}
+
+int pgf_profile_read(pgf_handle h, double *update_ms, int64_t *update_launches,
+                     double *update_flops, double *factor_ms) {
+  if (!h) return PGF_INVALID;
+  (void)hipSetDevice(h->device);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  PgfProfile &p = h->prof;
+  for (size_t i = 0; i < p.update_spans.size(); ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.update_spans[i].first, p.update_spans[i].second) == hipSuccess)
+      p.acc_update_ms += ms;
+    p.acc_update_flops += p.update_flops[i];
+    p.acc_update_launches += 1;
+    p.pool.push_back(p.update_spans[i].first);
+    p.pool.push_back(p.update_spans[i].second);
+  }
+  p.update_spans.clear();
+  p.update_flops.clear();
+  if (p.factor_open) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.factor_span.first, p.factor_span.second) == hipSuccess)
+      p.acc_factor_ms += ms;
+    p.pool.push_back(p.factor_span.first);
+    p.pool.push_back(p.factor_span.second);
+    p.factor_open = false;
+  }
+  if (update_ms) *update_ms = p.acc_update_ms;
+  if (update_launches) *update_launches = p.acc_update_launches;
+  if (update_flops) *update_flops = p.acc_update_flops;
+  if (factor_ms) *factor_ms = p.acc_factor_ms;
+  p.acc_update_ms = p.acc_update_flops = p.acc_factor_ms = 0;
+  p.acc_update_launches = 0;
+  return PGF_OK;
+}
+
+// ---------------------------------------------------------------- stand-alone linear solver
+int pgf_ls_create_dense(int N, const double *A, int64_t lda, int symmetric, int device,
+                        pgf_ls_handle *out) {
+  if (!out || N < 0 || N > 60000 || (N && (!A || lda < N))) return PGF_INVALID;
+  if (!symmetric) return PGF_INVALID;  // unsymmetric LU: not on the Symmetric path
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return PGF_HIP_ERROR + (int)e;
+  pgf_ls_handle ls = new (std::nothrow) pgf_linsolver();
+  if (!ls) return PGF_INVALID;
+  ls->N = N;
+  ls->device = device;
+  int rc = PGF_OK;
+  do {
+    if ((e = hipStreamCreateWithFlags(&ls->stream, hipStreamNonBlocking)) != hipSuccess) break;
+    if ((e = ldlt_alloc(ls->fac, N, ls->stream)) != hipSuccess) break;
+    if ((e = dalloc(&ls->rhs, (size_t)N + 1)) != hipSuccess) break;
+    if ((e = dalloc(&ls->sol, (size_t)N + 1)) != hipSuccess) break;
+    if (N) {
+      e = hipMemcpy2DAsync(ls->fac.K, (size_t)ls->fac.ldk * sizeof(double), A,
+                           (size_t)lda * sizeof(double), (size_t)N * sizeof(double), N,
+                           hipMemcpyHostToDevice, ls->stream);
+      if (e != hipSuccess) break;
+    }
+    if ((e = ldlt_factor_async(ls->fac, N, N)) != hipSuccess) break;
+    const int st = ldlt_finish(ls->fac, &e);
+    if (st < 0) break;
+    if (st == 1) rc = PGF_SINGULAR;
+  } while (0);
+  if (e != hipSuccess) rc = PGF_HIP_ERROR + (int)e;
+  if (rc != PGF_OK) {
+    pgf_ls_destroy(ls);
+    return rc;
+  }
+  *out = ls;
+  return PGF_OK;
+}
+
+int pgf_ls_solve(pgf_ls_handle ls, const double *rhs, int trans, double *sol) {
+  (void)trans;
+  if (!ls || (ls->N && (!rhs || !sol))) return PGF_INVALID;
+  if (ls->N == 0) return PGF_OK;
+  (void)hipSetDevice(ls->device);
+  hipError_t e = hipMemcpyAsync(ls->rhs, rhs, ls->N * sizeof(double), hipMemcpyHostToDevice,
+                                ls->stream);
+  if (e == hipSuccess) e = ldlt_solve_async(ls->fac, ls->rhs, ls->sol);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(sol, ls->sol, ls->N * sizeof(double), hipMemcpyDeviceToHost, ls->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ls->stream);
+  return e == hipSuccess ? PGF_OK : PGF_HIP_ERROR + (int)e;
+}
+
+int pgf_ls_num_neg(pgf_ls_handle ls, int *out) {
+  if (!ls || !out) return PGF_INVALID;
+  *out = ls->fac.n_neg;
+  return PGF_OK;
+}
+
+int pgf_ls_destroy(pgf_ls_handle ls) {
+  if (!ls) return PGF_OK;
+  (void)hipSetDevice(ls->device);
+  if (ls->stream) (void)hipStreamSynchronize(ls->stream);
+  ldlt_free(ls->fac);
+  if (ls->rhs) (void)hipFree(ls->rhs);
+  if (ls->sol) (void)hipFree(ls->sol);
+  if (ls->stream) (void)hipStreamDestroy(ls->stream);
+  delete ls;
+  return PGF_OK;
+}
+
+}  // extern "C"

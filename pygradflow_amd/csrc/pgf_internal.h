@@ -1,0 +1,58 @@
+// Internal declarations shared by the HIP translation units of libpgf_hip.so.
+// gfx950 (MI355X / CDNA4) only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#define PGF_NB 64  // diagonal-block / triangular-solve block size (one wavefront of rows)
+
+struct PgfProfile {
+  bool enabled = false;
+  std::vector<hipEvent_t> pool;  // recycled event pairs
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> update_spans;
+  std::vector<double> update_flops;
+  std::pair<hipEvent_t, hipEvent_t> factor_span{nullptr, nullptr};
+  bool factor_open = false;
+  double acc_update_ms = 0, acc_update_flops = 0, acc_factor_ms = 0;
+  int64_t acc_update_launches = 0;
+};
+
+// Dense symmetric factor  K = L D L^T  (unit lower L, diagonal D), lower triangle,
+// row-major in HBM with row stride ldk.  Row N (when nrows == N + 1) carries a
+// right-hand side through the elimination (forward substitution for free).
+struct DenseLdlt {
+  int Nmax = 0;
+  int64_t ldk = 0;
+  double *K = nullptr;      // (Nmax + 1) x ldk
+  double *W = nullptr;      // (Nmax + 1) x panel-width workspace: W = L * D of the panel
+  double *dvec = nullptr;   // D
+  double *dinv = nullptr;   // 1 / D
+  double *zwork = nullptr;  // solve work vector (Nmax)
+  int *flags = nullptr;     // [0] zero-pivot flag, [1] negative pivots
+  int *h_flags = nullptr;   // pinned host mirror
+  hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;  // look-ahead stream (trailing update)
+  hipEvent_t ev_panel = nullptr, ev_update = nullptr;
+  int N = 0;
+  bool factored = false;
+  int n_neg = 0;
+  PgfProfile *prof = nullptr;
+};
+
+hipError_t ldlt_alloc(DenseLdlt &f, int Nmax, hipStream_t stream);
+void ldlt_free(DenseLdlt &f);
+// enqueue the factorisation of the leading N x N lower triangle (+ rows up to nrows)
+hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows);
+// wait and read flags: returns 0 ok / 1 singular; sets f.n_neg
+int ldlt_finish(DenseLdlt &f, hipError_t *err);
+// sol <- K^{-1} rhs on device vectors of length N (rhs preserved if rhs != sol)
+hipError_t ldlt_solve_async(DenseLdlt &f, const double *rhs, double *sol);
+// backward half only: sol <- L^{-T} w, w already equals D^{-1} L^{-1} rhs (row N trick)
+hipError_t ldlt_backsolve_async(DenseLdlt &f, const double *w, double *sol);
+
+// ---- elementwise / assembly launches (pgf_kernels.hip) --------------------
+struct StepDev;  // opaque here

@@ -1,0 +1,42 @@
+// Launch wrappers of pgf_kernels.hip (all asynchronous on the given stream).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+void launch_scale_bounds(hipStream_t s, int n, double lamb, const double *lb, const double *ub,
+                         double *slb, double *sub);
+void launch_active_set(hipStream_t s, int n, int use_tau, double lamb, double f_x, double f_x0,
+                       double f_d, const double *xhat, const double *x, const double *g,
+                       const double *slb, const double *sub, uint8_t *mask);
+void launch_compact(hipStream_t s, int n, const uint8_t *mask, int *idxI, int *idxA, int *pos,
+                    int *counts);
+void launch_residual(hipStream_t s, int n, int m, double lamb, double dt, const double *xhat,
+                     const double *yhat, const double *x, const double *y, const double *g,
+                     const double *c, const double *slb, const double *sub, const uint8_t *mask,
+                     double *F, double *b0full);
+void launch_reduced_rhs(hipStream_t s, int n, int m, int nI, int nA, double fact, const double *F,
+                        const int *idxI, const double *H, int64_t ldh, const double *J,
+                        int64_t ldj, const double *b0full, double *rhs);
+void launch_assemble_kkt(hipStream_t s, double *K, int64_t ldk, const double *H, int64_t ldh,
+                         const double *J, int64_t ldj, const int *idxI, int nI, int m,
+                         double lamb, double delta);
+void launch_copy(hipStream_t s, double *dst, const double *src, int n);
+void launch_copy_u8(hipStream_t s, uint8_t *dst, const uint8_t *src, int n);
+void launch_mask_diff(hipStream_t s, int n, const uint8_t *a, const uint8_t *b, int *out);
+int step_update_blocks(int n, int m);
+void launch_step_update(hipStream_t s, int n, int m, int nI, double fact, double rho,
+                        const double *x, const double *y, const double *lb, const double *ub,
+                        const uint8_t *mask, const int *pos, const double *b0full,
+                        const double *F, const double *sol, double *dx, double *dy, double *xn,
+                        double *yn, double *red, double *diff_out);
+void launch_gemv_rows(hipStream_t s, int rows, int cols, const double *M, int64_t ld,
+                      const double *v, const double *add, double sgn, double *out);
+void launch_gemvT(hipStream_t s, int rows, int cols, const double *M, int64_t ld,
+                  const double *w, const double *base, double *partial, int nparts, double *out);
+void launch_mult_vec(hipStream_t s, int m, double rho, const double *c, const double *y,
+                     double *w);
+void launch_unscaled_res_norm(hipStream_t s, int n, int m, double dt, const double *xhat,
+                              const double *yhat, const double *x, const double *y,
+                              const double *g, const double *c, const double *lb,
+                              const double *ub, double *red, double *out);

@@ -1,0 +1,255 @@
+"""Semi-smooth Newton policies over a ``StepSolver``-shaped object, and the
+device-resident driver for linear-quadratic problems.
+
+``newton_method`` / ``SimplifiedNewtonMethod`` / ``FullNewtonMethod`` /
+``ActiveSetNewtonMethod`` follow the reference state machine
+(``pygradflow/newton.py:35-60, 63-89, 181-215``, factory ``:307-323``): which
+iterate supplies (mask, derivatives) and when the KKT matrix is re-factorised.
+They are host-side policy only; every number comes from the step solver.
+
+``DeviceNewton`` runs the same policies with the point, H, J, q, b resident in
+HBM: one ``pgf_qp_step`` per Newton step, no vectors crossing
+PCIe.  This is what ``bench.py`` times and what the batched mode shards.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from .errors import LinearSolverError, StepSolverError
+from .params import enum_name
+from .step_solver import POOL, HipStepSolver
+
+
+# --------------------------------------------------------------------------- policies
+class NewtonMethod:
+    def __init__(self, problem, orig_iterate, dt, rho, step_solver, tau=None):
+        self.problem = problem
+        self.orig_iterate = orig_iterate
+        self.dt = dt
+        self.rho = rho
+        self.tau = tau
+        self.step_solver = step_solver
+        self.func = step_solver.func
+
+    @property
+    def params(self):
+        return self.orig_iterate.params
+
+    def step(self, iterate):
+        raise NotImplementedError()
+
+
+class SimplifiedNewtonMethod(NewtonMethod):
+    """Mask and derivatives frozen at the outer iterate: one factorisation, then
+    back-solves (reference newton.py:35-60)."""
+
+    def __init__(self, problem, orig_iterate, dt, rho, step_solver, tau=None):
+        super().__init__(problem, orig_iterate, dt, rho, step_solver, tau)
+        mask = self.func.compute_active_set(orig_iterate, rho, tau)
+        step_solver.update_active_set(mask)
+        step_solver.update_derivs(orig_iterate)
+
+    def step(self, iterate):
+        return self.step_solver.solve(iterate)
+
+
+class FullNewtonMethod(NewtonMethod):
+    """Mask, derivatives and factorisation from the current iterate, every step
+    (reference newton.py:63-89)."""
+
+    def step(self, iterate):
+        mask = self.func.compute_active_set(iterate, self.rho, self.tau)
+        self.step_solver.update_active_set(mask)
+        self.step_solver.update_derivs(iterate)
+        return self.step_solver.solve(iterate)
+
+
+class ActiveSetNewtonMethod(NewtonMethod):
+    """Derivatives frozen at the outer iterate, mask from the current one; refactor
+    only when the mask differs elementwise (reference newton.py:181-215)."""
+
+    def __init__(self, problem, orig_iterate, dt, rho, step_solver, tau=None):
+        super().__init__(problem, orig_iterate, dt, rho, step_solver, tau)
+        step_solver.update_derivs(orig_iterate)
+        self._curr_active_set = None
+
+    def step(self, iterate):
+        mask = self.func.compute_active_set(iterate, self.rho, self.tau)
+        if self._curr_active_set is None or (self._curr_active_set != mask).any():
+            self.step_solver.update_active_set(mask)
+        self._curr_active_set = mask
+        return self.step_solver.solve(iterate)
+
+
+def make_step_solver(problem, params, iterate, dt, rho):
+    """Reference factory ``step_solver`` (step/solver/__init__.py:12-31): honours the
+    ``params.step_solver`` hook, defaults to the HIP solver (Symmetric formulation)."""
+    hook = getattr(params, "step_solver", None)
+    if hook is not None:
+        return hook(problem, params, iterate, dt, rho)
+    kind = enum_name(getattr(params, "step_solver_type", "Symmetric"))
+    if kind != "Symmetric":
+        raise NotImplementedError(
+            f"step_solver_type {kind}: only the Symmetric formulation is on the HIP hot path"
+        )
+    return HipStepSolver(problem, params, iterate, dt, rho)
+
+
+def newton_method(problem, params, iterate, dt, rho, tau=None):
+    if not (dt > 0.0 and rho > 0.0):
+        raise ValueError("dt and rho must be positive")
+    solver = make_step_solver(problem, params, iterate, dt, rho)
+    kind = enum_name(params.newton_type)
+    if kind == "Simplified":
+        return SimplifiedNewtonMethod(problem, iterate, dt, rho, solver, tau)
+    if kind == "Full":
+        return FullNewtonMethod(problem, iterate, dt, rho, solver, tau)
+    if kind == "ActiveSet":
+        return ActiveSetNewtonMethod(problem, iterate, dt, rho, solver, tau)
+    raise NotImplementedError(f"newton_type {kind} is not on the HIP hot path yet (SURVEY 8f)")
+
+
+def newton_steps(problem, params, orig_iterate, dt, rho, tau=None):
+    """Generator of successive ``StepResult``s (``NewtonController.newton_steps``,
+    reference step/newton_control.py:22-38, for a given tau)."""
+    method = newton_method(problem, params, orig_iterate, dt, rho, tau)
+    curr = orig_iterate
+    while True:
+        step = method.step(curr)
+        yield step
+        curr = step.iterate
+
+
+# --------------------------------------------------------------------------- device-resident
+_POLICY_BITS = {
+    "Simplified": 0,
+    "Full": _lib.STEP_RECOMPUTE_MASK | _lib.STEP_REFACTOR,
+    "ActiveSet": _lib.STEP_RECOMPUTE_MASK | _lib.STEP_REFACTOR_ON_CHANGE,
+}
+
+
+class DeviceNewton:
+    """Newton policies for a ``LinearQuadraticProblem`` held entirely in HBM.
+
+    ``DeviceNewton(problem, newton_type, x_hat, y_hat, dt, rho, tau)`` mirrors
+    ``newton_method(...)``; ``step()`` advances the device-resident point and returns
+    ``(diff, n_neg)``; ``point()`` / ``mask()`` copy results out for checking.
+    """
+
+    def __init__(self, problem, newton_type, x_hat, y_hat, dt, rho, tau=None, device=0,
+                 start=None):
+        _lib.require_gpu()
+        self._lib = _lib.load()
+        self.problem = problem
+        self.kind = enum_name(newton_type) if not isinstance(newton_type, str) else newton_type
+        if self.kind not in _POLICY_BITS:
+            raise NotImplementedError(self.kind)
+        self.n, self.m = problem.num_vars, problem.num_cons
+        self.dt, self.rho = float(dt), float(rho)
+        self.tau = math.nan if tau is None else float(tau)
+        self._hd = POOL.acquire(self.n, self.m, device)
+        h = self._hd.h
+        lib = self._lib
+        lb, ub = _lib.as_f64(problem.var_lb), _lib.as_f64(problem.var_ub)
+        _lib.check(lib.pgf_set_bounds(h, _lib.dptr(lb), _lib.dptr(ub)), h, "pgf_set_bounds")
+        key = getattr(problem, "_pgf_token", None)
+        if key is None:
+            key = object()
+            problem._pgf_token = key
+        if self._hd.derivs_key is not key or not getattr(self._hd, "qp_loaded", False):
+            Q = np.ascontiguousarray(problem.hess_dense(), dtype=np.float64)
+            A = np.ascontiguousarray(problem.jac_dense(), dtype=np.float64).reshape(self.m, self.n)
+            q, b = _lib.as_f64(problem.q), _lib.as_f64(problem.b)
+            rc = lib.pgf_qp_set_problem(
+                h, Q.ctypes.data_as(C.c_void_p), max(self.n, 1), q.ctypes.data_as(C.c_void_p),
+                A.ctypes.data_as(C.c_void_p), max(self.n, 1), b.ctypes.data_as(C.c_void_p),
+                _lib.PGF_HOST)
+            _lib.check(rc, h, "pgf_qp_set_problem")
+            self._hd.derivs_key = key
+            self._hd.qp_loaded = True
+        self.set_outer(x_hat, y_hat, dt, rho, start=start)
+
+    def set_outer(self, x_hat, y_hat, dt, rho, start=None):
+        """Begin a new outer step at (x_hat, y_hat) (a new NewtonMethod in the reference)."""
+        h, lib = self._hd.h, self._lib
+        self.dt, self.rho = float(dt), float(rho)
+        xh, yh = _lib.as_f64(x_hat), _lib.as_f64(y_hat)
+        _lib.check(lib.pgf_set_outer(h, _lib.dptr(xh), _lib.dptr(yh), self.dt, self.rho), h,
+                   "pgf_set_outer")
+        _lib.check(lib.pgf_qp_set_point(h, _lib.dptr(xh), _lib.dptr(yh)), h, "pgf_qp_set_point")
+        if self.kind == "Simplified":
+            ch = C.c_int(0)
+            _lib.check(lib.pgf_qp_update_active_set(h, self.tau, C.byref(ch)), h,
+                       "pgf_qp_update_active_set")
+        if start is not None:
+            xs, ys = _lib.as_f64(start[0]), _lib.as_f64(start[1])
+            _lib.check(lib.pgf_qp_set_point(h, _lib.dptr(xs), _lib.dptr(ys)), h, "pgf_qp_set_point")
+
+    def step(self, inertia_check=False):
+        n_neg, diff = C.c_int(0), C.c_double(0.0)
+        try:
+            rc = self._lib.pgf_qp_step(self._hd.h, _POLICY_BITS[self.kind], self.tau,
+                                       int(inertia_check), C.byref(n_neg), C.byref(diff))
+            _lib.check(rc, self._hd.h, "pgf_qp_step")
+        except LinearSolverError as e:
+            raise StepSolverError(str(e)) from e
+        return diff.value, n_neg.value
+
+    def step_async(self):
+        _lib.check(self._lib.pgf_qp_step_async(self._hd.h, _POLICY_BITS[self.kind], self.tau),
+                   self._hd.h, "pgf_qp_step_async")
+
+    def sync(self):
+        n_neg, diff = C.c_int(0), C.c_double(0.0)
+        _lib.check(self._lib.pgf_qp_sync(self._hd.h, C.byref(n_neg), C.byref(diff)), self._hd.h,
+                   "pgf_qp_sync")
+        return diff.value, n_neg.value
+
+    def point(self):
+        x, y = np.empty(self.n), np.empty(self.m)
+        _lib.check(self._lib.pgf_qp_get_point(self._hd.h, _lib.dptr(x), _lib.dptr(y)), self._hd.h)
+        return x, y
+
+    def set_point(self, x, y):
+        xs, ys = _lib.as_f64(x), _lib.as_f64(y)
+        _lib.check(self._lib.pgf_qp_set_point(self._hd.h, _lib.dptr(xs), _lib.dptr(ys)), self._hd.h)
+
+    def mask(self):
+        mk = np.empty(self.n, dtype=np.bool_)
+        _lib.check(self._lib.pgf_qp_get_mask(self._hd.h, _lib.u8ptr(mk)), self._hd.h)
+        return mk
+
+    def residual_norm(self, out_dev_ptr=None):
+        """||F(z)||_2 of the unscaled residual at the device point; optionally also
+        stored to a device address (the rank-local slot of the RCCL all-gather)."""
+        out = C.c_double(0.0)
+        _lib.check(self._lib.pgf_qp_residual_norm(self._hd.h, C.byref(out),
+                                                  C.c_void_p(out_dev_ptr) if out_dev_ptr else None),
+                   self._hd.h, "pgf_qp_residual_norm")
+        return out.value
+
+    def profile(self, on=True):
+        _lib.check(self._lib.pgf_profile_enable(self._hd.h, int(on)), self._hd.h)
+
+    def profile_read(self):
+        ms, cnt, fl, fms = C.c_double(0), C.c_int64(0), C.c_double(0), C.c_double(0)
+        _lib.check(self._lib.pgf_profile_read(self._hd.h, C.byref(ms), C.byref(cnt), C.byref(fl),
+                                              C.byref(fms)), self._hd.h)
+        return dict(update_ms=ms.value, update_launches=cnt.value, update_flops=fl.value,
+                    factor_ms=fms.value)
+
+    def close(self):
+        if getattr(self, "_hd", None) is not None:
+            POOL.release(self._hd)
+            self._hd = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

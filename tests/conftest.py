@@ -14,6 +14,10 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def gpu_available():
-    import torch
+    import ctypes
 
-    return torch.cuda.is_available()
+    from pygradflow_amd import _lib
+
+    cnt = ctypes.c_int(0)
+    rc = _lib.load().pgf_device_count(ctypes.byref(cnt))
+    return rc == 0 and cnt.value > 0

@@ -1,0 +1,202 @@
+"""GPU parity tests proper: HIP path (through the C ABI) vs golden vectors and oracle.
+
+Bars: active-set masks bit-exact; iterates within 1e-10 relative (BASELINE.json).
+"""
+
+import numpy as np
+import pytest
+
+from oracle import newton_oracle as O
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def pgf():
+    import pygradflow_amd as pgf
+
+    return pgf
+
+
+def _sqd(rng, n1, n2, cond=1.0):
+    """Symmetric quasi-definite test matrix [[A, B'],[B, -C]]."""
+    G1 = rng.standard_normal((n1, n1)) / np.sqrt(max(n1, 1))
+    A = G1 @ G1.T + cond * np.eye(n1)
+    B = rng.standard_normal((n2, n1)) / np.sqrt(max(n1, 1))
+    C = 0.5 * np.eye(n2)
+    return np.block([[A, B.T], [B, -C]])
+
+
+def test_linear_solver_golden_5x5(pgf):
+    ls = np.load(G.GOLDEN + "/linear_solver_5x5.npz")
+    for nm in ("indef", "posdef", "negdef"):
+        mat = ls[nm + "/mat"]
+        sv = pgf.HipLinearSolver(mat, symmetric=True)
+        sol = sv.solve(ls["rhs"])
+        assert G.rel_err(sol, ls[nm + "/sol"]) <= 1e-12
+        assert np.allclose(mat @ sol, ls["rhs"])
+        assert sv.num_neg_eigvals() == int(ls[nm + "/n_neg"])
+        assert G.rel_err(sv.solve(ls["rhs"], trans=True), ls[nm + "/sol_trans"]) <= 1e-12
+
+
+@pytest.mark.parametrize("n1,n2", [(1, 0), (3, 2), (63, 0), (64, 0), (65, 0), (64, 64), (100, 30),
+                                   (130, 61), (257, 128), (700, 189), (1500, 500)])
+def test_linear_solver_random_sqd(pgf, n1, n2):
+    rng = np.random.default_rng(n1 * 1000 + n2)
+    K = _sqd(rng, n1, n2)
+    rhs = rng.standard_normal(n1 + n2)
+    sv = pgf.HipLinearSolver(K, symmetric=True)
+    sol = sv.solve(rhs)
+    ref = np.linalg.solve(K, rhs)
+    assert G.rel_err(sol, ref) <= 1e-11
+    assert sv.num_neg_eigvals() == n2
+
+
+def test_linear_solver_singular_raises(pgf):
+    K = np.zeros((4, 4))
+    with pytest.raises(pgf.LinearSolverError):
+        pgf.HipLinearSolver(K, symmetric=True)
+
+
+def test_linear_solver_empty(pgf):
+    sv = pgf.HipLinearSolver(np.zeros((0, 0)), symmetric=True)
+    assert sv.solve(np.zeros(0)).shape == (0,)
+    assert sv.num_neg_eigvals() == 0
+
+
+@pytest.mark.parametrize("name", G.case_names())
+def test_step_solver_replays_golden(pgf, name):
+    """Every recorded reference step, fed through HipStepSolver with the recorded inputs."""
+    case = G.load_case(name)
+    shape = G.shape_only_problem(case)
+    dt, rho, tau = float(case["dt"]), float(case["rho"]), G.case_tau(case)
+    params = pgf.Params()
+    for pol in case["policies"]:
+        for k in range(int(case["steps"])):
+            pre = f"{pol}/{k}/"
+            orig = G.RecordedPoint(case, pol, 0, shape, params)
+            orig.x, orig.y = case["x0"], case["y0"]
+            pt = G.RecordedPoint(case, pol, k, shape, params)
+            sv = pgf.HipStepSolver(shape, params, orig, dt, rho)
+            if pol != "Simplified":
+                mask = sv.func.compute_active_set(pt, rho, tau)
+                assert np.array_equal(mask, case[pre + "mask"]), (pol, k)
+            sv.update_active_set(case[pre + "mask"])
+            sv.update_derivs(pt)
+            F = sv.func.value_at(pt, rho, case[pre + "mask"])
+            assert G.rel_err(F, case[pre + "F"]) <= 1e-13
+            K = sv.kkt_matrix()
+            Kref = np.tril(case[pre + "K"])
+            assert K.shape == Kref.shape
+            assert G.rel_err(np.tril(K), Kref) <= 1e-14
+            res = sv.solve(pt)
+            assert np.array_equal(res.active_set, case[pre + "mask"])
+            assert G.rel_err(res.dx, case[pre + "dx"]) <= TOL, (pol, k)
+            assert G.rel_err(res.dy, case[pre + "dy"]) <= TOL, (pol, k)
+            assert G.rel_err(res.xn, case[pre + "xn"]) <= TOL, (pol, k)
+            assert G.rel_err(res._yn, case[pre + "yn"]) <= TOL, (pol, k)
+            assert abs(res.diff - float(case[pre + "diff"])) <= TOL * max(1.0, res.diff)
+            assert sv.solver.num_neg_eigvals() == int(case[pre + "n_neg"])
+            sv.close()
+
+
+@pytest.mark.parametrize("name", [n for n in G.case_names() if G.has_problem(G.load_case(n))])
+def test_policies_free_running(pgf, name):
+    """newton_method(...) with HipStepSolver, stepping on its own output, against the
+    reference trajectory (masks bit-exact, iterates <= 1e-10)."""
+    case = G.load_case(name)
+    problem = G.rebuild_problem(case)
+    dt, rho, tau = float(case["dt"]), float(case["rho"]), G.case_tau(case)
+    for pol in case["policies"]:
+        params = pgf.Params(newton_type=str(pol), step_solver=pgf.HipStepSolver)
+        orig = pgf.Iterate(problem, params, case["x0"], case["y0"])
+        gen = pgf.newton_steps(problem, params, orig, dt, rho, tau)
+        for k in range(int(case["steps"])):
+            step = next(gen)
+            pre = f"{pol}/{k}/"
+            assert np.array_equal(step.active_set, case[pre + "mask"]), (pol, k)
+            assert G.rel_err(step.iterate.x, case[pre + "xn"]) <= TOL, (pol, k)
+            assert G.rel_err(step.iterate.y, case[pre + "yn"]) <= TOL, (pol, k)
+
+
+@pytest.mark.parametrize(
+    "name", [n for n in G.case_names()
+             if G.has_problem(G.load_case(n)) and str(G.load_case(n)["problem/kind"]) == "lq"])
+def test_device_resident_newton(pgf, name):
+    """DeviceNewton (point, H, J in HBM; g, c evaluated on device) vs reference."""
+    case = G.load_case(name)
+    problem = G.rebuild_problem(case)
+    dt, rho, tau = float(case["dt"]), float(case["rho"]), G.case_tau(case)
+    for pol in case["policies"]:
+        dn = pgf.DeviceNewton(problem, str(pol), case["x0"], case["y0"], dt, rho, tau)
+        for k in range(int(case["steps"])):
+            pre = f"{pol}/{k}/"
+            diff, n_neg = dn.step()
+            x, y = dn.point()
+            assert np.array_equal(dn.mask(), case[pre + "mask"]), (pol, k)
+            assert G.rel_err(x, case[pre + "xn"]) <= TOL, (pol, k)
+            assert G.rel_err(y, case[pre + "yn"]) <= TOL, (pol, k)
+            assert abs(diff - float(case[pre + "diff"])) <= TOL * max(1.0, diff)
+            assert n_neg == int(case[pre + "n_neg"])
+            assert abs(dn.residual_norm() - float(case[pre + "res_norm"])) <= 1e-9 * max(
+                1.0, float(case[pre + "res_norm"]))
+        dn.close()
+
+
+@pytest.mark.parametrize("n,m,boxed", [(512, 128, 0.0), (1024, 256, 0.25)])
+def test_mid_size_against_oracle(pgf, n, m, boxed):
+    """Config-4 sized instance (n=1024, m=256) against the CPU oracle, 3 Full steps."""
+    from pygradflow_amd import problems
+
+    prob = problems.dense_qp(n, m, seed=7, boxed_frac=boxed, box=0.02)
+    x0, y0 = np.zeros(n), np.zeros(m)
+    for pol in ("Full", "Simplified", "ActiveSet"):
+        orc = O.NewtonOracle(prob, pol, x0, y0, 1.0, 1.0)
+        recs = orc.run(x0, y0, 3)
+        dn = pgf.DeviceNewton(prob, pol, x0, y0, 1.0, 1.0)
+        for k, rec in enumerate(recs):
+            dn.step()
+            x, y = dn.point()
+            assert np.array_equal(dn.mask(), rec["mask"]), (pol, k)
+            assert G.rel_err(x, rec["xn"]) <= TOL, (pol, k)
+            assert G.rel_err(y, rec["yn"]) <= TOL, (pol, k)
+        dn.close()
+
+
+def test_full_size_config2_properties(pgf):
+    """BASELINE config 2 at full size (n=4096, m=1024): for an unbounded QP the residual
+    is affine, so ONE Full Newton step solves F(z+) = 0 (the reference's
+    test_one_step_convergence property, tests/pygradflow/test_solver.py:191-215); the
+    inertia of K must be exactly m; a second step must not move."""
+    from pygradflow_amd import problems
+
+    n, m = 4096, 1024
+    prob = problems.dense_qp(n, m, seed=0)
+    dn = pgf.DeviceNewton(prob, "Full", np.zeros(n), np.zeros(m), 1.0, 1.0)
+    r0 = dn.residual_norm()
+    diff, n_neg = dn.step()
+    assert n_neg == m
+    assert not dn.mask().any()
+    r1 = dn.residual_norm()
+    assert r1 <= 1e-11 * max(1.0, r0), (r0, r1)
+    x1, y1 = dn.point()
+    diff2, _ = dn.step()
+    x2, y2 = dn.point()
+    assert diff2 <= 1e-10 * max(1.0, diff)
+    assert G.rel_err(x2, x1) <= TOL and G.rel_err(y2, y1) <= TOL
+    # independent check of the step on the host (dense numpy, not the oracle's LU)
+    Q, A = prob.hess_dense(), prob.jac_dense()
+    lamb, rho = 1.0, 1.0
+    g = prob.q + A.T @ (rho * (-prob.b))
+    Fx, Fy = g, -prob.b                     # lamb*x - (lamb*xhat - g), -(lamb*y - (lamb*yhat + c)) at 0
+    Kd = np.block([[Q + lamb * np.eye(n), A.T], [A, -lamb / (1 + lamb * rho) * np.eye(m)]])
+    fact = 1.0 / (1.0 + lamb * rho)
+    s = np.linalg.solve(Kd, np.concatenate([Fx, fact * Fy]))
+    xn = -s[:n]
+    yn = -fact * (s[n:] - rho * Fy)
+    assert G.rel_err(x1, xn) <= TOL
+    assert G.rel_err(y1, yn) <= TOL
+    dn.close()
