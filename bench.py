@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Newton steps/sec on the dense KKT hot path (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+
+One "step" = one Full Newton step (NewtonType.Full, StepSolverType.Symmetric,
+SURVEY.md 8d): evaluate c, g at the device point -> active-set mask -> gather-assemble
+K -> LDL^T factor -> solve -> update + clip.  Problem data (Q, A, q, b) and the iterate
+are resident in HBM before the timed region starts.  Every second step begins a new
+outer (implicit Euler) step on device, as the reference's default DistanceRatio
+controller does (2 Newton steps per outer iteration), so each step does real work.
+
+N > 1: one process per GPU (launched by torch.distributed.run); each rank owns an
+independent instance of the same size (seed = rank): weak scaling over instances, and
+per step ONE RCCL all-gather of the ranks' residual norms ||F(z)||_2.
+
+Prints one JSON line (rank 0) with `roofline` (dominant kernel = the FP64-MFMA trailing
+update of the factorisation, timed with HIP events on the solver's stream in a separate
+instrumented pass over the same steps) and `cpu_baseline` (the numpy/scipy restatement
+of the reference path, oracle/, timed on the host cores; kind "port").
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+# FP64 matrix (MFMA) dense peak of MI355X.  MI355X_MICROARCH.md lists no FP64 row; the
+# vendor figure is 78.6 TFLOP/s = 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz.
+PEAK_FP64_MFMA_TFLOPS = 78.6
+
+WORKLOADS = {
+    "dense_qp_n4096_m1024": dict(n=4096, m=1024),   # BASELINE configs[1]
+    "dense_qp_n1024_m256": dict(n=1024, m=256),     # element of configs[3]
+    "dense_qp_n512_m128": dict(n=512, m=128),       # quick check
+}
+
+
+def cpu_baseline(problem, max_seconds):
+    """One Full Newton step of the CPU restatement (same bmat + splu calls as the
+    reference) from x0 = y0 = 0; returns (steps/s, record)."""
+    from oracle import newton_oracle as O
+
+    n, m = problem.num_vars, problem.num_cons
+    t0 = time.perf_counter()
+    orc = O.NewtonOracle(problem, "Full", np.zeros(n), np.zeros(m), 1.0, 1.0)
+    recs = []
+    x, y = np.zeros(n), np.zeros(m)
+    steps = 0
+    while True:
+        x, y, _ = orc.step(x, y)
+        recs.append(dict(orc.solver.record))
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > max_seconds or steps >= 20:
+            break
+    return steps / el, recs, steps, el
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="dense_qp_n4096_m1024", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        args.gpus = world
+
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from pygradflow_amd import problems
+    from pygradflow_amd.newton import DeviceNewton
+
+    wl = WORKLOADS[args.workload]
+    n, m = wl["n"], wl["m"]
+    problem = problems.dense_qp(n, m, seed=rank)
+    x0, y0 = np.zeros(n), np.zeros(m)
+    dn = DeviceNewton(problem, "Full", x0, y0, 1.0, 1.0, device=local_rank)
+
+    dev = torch.device("cuda", local_rank)
+    norms_local = torch.zeros(1, dtype=torch.float64, device=dev)
+    norms_all = torch.zeros(world, dtype=torch.float64, device=dev)
+
+    def one_step(i):
+        if i % 2 == 0 and i > 0:
+            dn.advance_outer()
+        dn.step()
+        dn.residual_norm(norms_local.data_ptr())
+        if dist is not None:
+            dist.all_gather_into_tensor(norms_all, norms_local)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    # parity of the first step against the CPU restatement (rank 0 only, bounded)
+    parity = None
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        rate, recs, csteps, cel = cpu_baseline(problem, args.cpu_seconds)
+        dn.step()
+        xg, yg = dn.point()
+        r0 = recs[0]
+        den = max(1.0, np.max(np.abs(r0["xn"])))
+        parity = dict(
+            mask_hamming=int(np.count_nonzero(dn.mask() != r0["mask"])),
+            iterate_rel_err=float(max(np.max(np.abs(xg - r0["xn"])) / den,
+                                      np.max(np.abs(yg - r0["yn"])) / max(1.0, np.max(np.abs(r0["yn"]))))),
+        )
+        cpu = dict(value=rate, unit="Newton steps/s", cores=1, kind="port",
+                   sample=f"{csteps} Full Newton step(s) of {args.workload} from x0=y0=0 "
+                          f"(scipy bmat + SuperLU splu as the reference calls them; "
+                          f"SuperLU is single-threaded), {cel:.1f} s; host has {os.cpu_count()} cores")
+        dn.set_outer(x0, y0, 1.0, 1.0)
+
+    for i in range(args.warmup):
+        one_step(i)
+    dn.set_outer(x0, y0, 1.0, 1.0)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # instrumented pass: HIP events around every trailing-update launch (same steps)
+    roof = None
+    if rank == 0:
+        dn.set_outer(x0, y0, 1.0, 1.0)
+        dn.profile(True)
+        for i in range(args.steps):
+            one_step(i)
+        pr = dn.profile_read()
+        dn.profile(False)
+        if pr["update_launches"] > 0 and pr["update_ms"] > 0:
+            achieved = pr["update_flops"] / (pr["update_ms"] * 1e-3) / 1e12
+            roof = dict(
+                bound="mfma", kernel="k_ldlt_update", achieved=achieved,
+                peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP64_MFMA_TFLOPS,
+                traffic=None,
+                launches_per_step=pr["update_launches"] / args.steps,
+                avg_launch_us=1e3 * pr["update_ms"] / pr["update_launches"],
+                flops_per_step=pr["update_flops"] / args.steps,
+                factor_ms_per_step=pr["factor_ms"] / args.steps,
+            )
+
+    if rank == 0:
+        total_steps = args.steps * world
+        out = {
+            "metric": "Newton steps/sec on dense KKT n=4096 m=1024; iterate match <=1e-10",
+            "value": total_steps / elapsed,
+            "unit": "Newton steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "n": n, "m": m, "newton_type": "Full",
+                       "step_solver": "Symmetric", "instances_per_gpu": 1,
+                       "collective": "all_gather(residual norms)" if world > 1 else "none"},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "parity": parity,
+        }
+        print(json.dumps(out), flush=True)
+    dn.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -128,6 +128,9 @@ int pgf_qp_get_mask(pgf_handle h, uint8_t *mask);
 /* mask <- compute_active_set at the device point (SimplifiedNewtonMethod.__init__,
  * newton.py:52-56: call once at (x^, y^)); *changed = 1 if the stored mask was replaced */
 int pgf_qp_update_active_set(pgf_handle h, double tau, int *changed);
+/* new outer step at the current device point: (x^, y^) <- (x, y) on device, then as
+ * pgf_set_outer (what Solver.solve does between accepted steps, solver.py:357-378) */
+int pgf_qp_advance_outer(pgf_handle h, double dt, double rho);
 /* One NewtonMethod.step on the device-resident point (policy bits above; tau NaN = None).
  * (x, y) <- (xn, yn).  n_neg / diff may be NULL.  One host sync at the end
  * (plus one to read |I| when the mask is recomputed). */

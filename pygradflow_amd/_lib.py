@@ -52,6 +52,7 @@ SIGNATURES = {
     "pgf_qp_get_point": (C.c_int, [_h, _dp, _dp]),
     "pgf_qp_get_mask": (C.c_int, [_h, _u8p]),
     "pgf_qp_update_active_set": (C.c_int, [_h, C.c_double, _ip]),
+    "pgf_qp_advance_outer": (C.c_int, [_h, C.c_double, C.c_double]),
     "pgf_qp_step": (C.c_int, [_h, C.c_uint, C.c_double, C.c_int, _ip, _dp]),
     "pgf_qp_step_async": (C.c_int, [_h, C.c_uint, C.c_double]),
     "pgf_qp_sync": (C.c_int, [_h, _ip, _dp]),

@@ -571,6 +571,26 @@ int pgf_qp_update_active_set(pgf_handle h, double tau, int *changed) {
   return qp_refresh_mask(h, tau, false, changed);
 }
 
+int pgf_qp_advance_outer(pgf_handle h, double dt, double rho) {
+  if (!h) return PGF_INVALID;
+  int rc;
+  if ((rc = qp_ready(h))) return rc;
+  if (!(dt > 0.0) || !(rho > 0.0)) return fail(h, PGF_INVALID, "dt and rho must be positive");
+  (void)hipSetDevice(h->device);
+  launch_copy(h->stream, h->xhat, h->x, h->n);
+  launch_copy(h->stream, h->yhat, h->y, h->m);
+  if (rho != h->rho) h->eval_fresh = false;  // g depends on rho
+  h->dt = dt;
+  h->lamb = 1.0 / dt;
+  h->rho = rho;
+  h->fact = 1.0 / (1.0 + h->lamb * rho);
+  h->delta = h->lamb / (1.0 + h->lamb * rho);
+  launch_scale_bounds(h->stream, h->n, h->lamb, h->lb, h->ub, h->slb, h->sub);
+  h->mask_set = false;
+  invalidate_factor(h);
+  return PGF_OK;
+}
+
 int pgf_qp_step_async(pgf_handle h, unsigned policy, double tau) {
   if (!h) return PGF_INVALID;
   int rc;

@@ -190,6 +190,17 @@ class DeviceNewton:
             xs, ys = _lib.as_f64(start[0]), _lib.as_f64(start[1])
             _lib.check(lib.pgf_qp_set_point(h, _lib.dptr(xs), _lib.dptr(ys)), h, "pgf_qp_set_point")
 
+    def advance_outer(self, dt=None, rho=None):
+        """(x_hat, y_hat) <- current device point; starts the next outer step on device."""
+        h, lib = self._hd.h, self._lib
+        self.dt = self.dt if dt is None else float(dt)
+        self.rho = self.rho if rho is None else float(rho)
+        _lib.check(lib.pgf_qp_advance_outer(h, self.dt, self.rho), h, "pgf_qp_advance_outer")
+        if self.kind == "Simplified":
+            ch = C.c_int(0)
+            _lib.check(lib.pgf_qp_update_active_set(h, self.tau, C.byref(ch)), h,
+                       "pgf_qp_update_active_set")
+
     def step(self, inertia_check=False):
         n_neg, diff = C.c_int(0), C.c_double(0.0)
         try:

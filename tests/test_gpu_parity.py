@@ -5,6 +5,7 @@ Bars: active-set masks bit-exact; iterates within 1e-10 relative (BASELINE.json)
 
 import numpy as np
 import pytest
+import scipy.sparse as sps
 
 from oracle import newton_oracle as O
 from tests import golden_util as G
@@ -85,7 +86,12 @@ def test_step_solver_replays_golden(pgf, name):
                 mask = sv.func.compute_active_set(pt, rho, tau)
                 assert np.array_equal(mask, case[pre + "mask"]), (pol, k)
             sv.update_active_set(case[pre + "mask"])
-            sv.update_derivs(pt)
+            # derivatives the reference solver had frozen (for Simplified / ActiveSet they
+            # stem from the outer iterate, not from the point the step is taken at)
+            frozen = G.RecordedPoint(case, pol, k, shape, params)
+            _, Jf = G.step_derivs(case, pol, k)
+            frozen.jac = frozen.cons_jac = sps.csr_matrix(Jf.reshape(int(case["m"]), int(case["n"])))
+            sv.update_derivs(frozen)
             F = sv.func.value_at(pt, rho, case[pre + "mask"])
             assert G.rel_err(F, case[pre + "F"]) <= 1e-13
             K = sv.kkt_matrix()
