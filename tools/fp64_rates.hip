@@ -82,6 +82,8 @@ void run(int threads, int iters, const char *tag) {
 
 int main() {
   run<0>(256, 4000, "MFMA 1 wave/SIMD ");
+  run<0>(256, 20000, "MFMA long 4.5ms  ");
+  run<0>(256, 80000, "MFMA long 18ms   ");
   run<0>(512, 4000, "MFMA 2 wave/SIMD ");
   run<1>(256, 4000, "VALU 1 wave/SIMD ");
   run<1>(512, 4000, "VALU 2 wave/SIMD ");
