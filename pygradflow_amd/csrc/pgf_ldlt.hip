@@ -15,128 +15,215 @@
 #include "pgf_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
-// ------------------------------------------------------------------ diag block
-// Unblocked right-looking LDL^T of one NB x NB diagonal block held in LDS.
-// One barrier per column: column j is only scaled at the very end, the rank-1
-// update uses the unscaled column and 1/d_j.
-template <int NB>
-__global__ __launch_bounds__(256) void k_ldlt_diag(double *__restrict__ K, int64_t ldk, int N,
-                                                    int c0, double *__restrict__ dvec,
-                                                    double *__restrict__ dinv,
-                                                    int *__restrict__ flags) {
-  __shared__ double Ad[NB][NB + 1];
-  __shared__ double dI[NB];
-  const int tid = threadIdx.x;
-  const int nb = min(NB, N - c0);
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int i = idx / NB, j = idx % NB;
-    double v = (i == j) ? 1.0 : 0.0;
-    if (i < nb && j <= i) v = K[(int64_t)(c0 + i) * ldk + c0 + j];
-    Ad[i][j] = v;
-  }
-  __syncthreads();
-  const int ti = tid >> 4, tk = tid & 15;
-  for (int j = 0; j < nb; ++j) {
-    const double d = Ad[j][j];
-    const bool bad = (d == 0.0) || !(fabs(d) <= 1.79e308);
-    const double di = bad ? 0.0 : 1.0 / d;
-    if (tid == 0) {
-      dI[j] = di;
-      if (bad) atomicOr(&flags[0], 1);
-    }
-    // trailing update: A[i][k] -= A[i][j] * A[k][j] / d   for j < k <= i < nb
-    for (int i = j + 1 + ti; i < nb; i += 16) {
-      const double li = Ad[i][j] * di;
-      for (int k = j + 1 + tk; k <= i; k += 16) Ad[i][k] = fma(-li, Ad[k][j], Ad[i][k]);
-    }
-    __syncthreads();
-  }
-  // scale columns, write back L (strictly lower), D and 1/D
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int i = idx / NB, j = idx % NB;
-    if (i < nb && j < i) K[(int64_t)(c0 + i) * ldk + c0 + j] = Ad[i][j] * dI[j];
-  }
-  if (tid < nb) {
-    const double d = Ad[tid][tid];
-    dvec[c0 + tid] = d;
-    dinv[c0 + tid] = dI[tid];
-    K[(int64_t)(c0 + tid) * ldk + c0 + tid] = d;
-  }
-  // inertia: count negative pivots of this block
-  if (tid < 64) {
-    int neg = 0;
-    for (int j = tid; j < nb; j += 64) neg += (Ad[j][j] < 0.0) ? 1 : 0;
-    for (int off = 32; off > 0; off >>= 1) neg += __shfl_down(neg, off);
-    if (tid == 0 && neg) atomicAdd(&flags[1], neg);
-  }
+// ------------------------------------------------------------------ helpers
+// broadcast lane `src` (wave-uniform, compile-time after unrolling) of a double through
+// two v_readlane_b32 (scalar result; no LDS round trip as with __shfl / ds_bpermute)
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
 }
 
-// ------------------------------------------------------------------ panel TRSM
-// Rows below the diagonal block: X L_kk^T = A_ik  (X = L_ik D_kk).  One lane owns
-// one row (NB doubles in VGPRs, fully unrolled substitution); L_kk is broadcast
-// from LDS.  Writes W = X (workspace, row stride NB) and L = X D^-1 in place.
+// ------------------------------------------------------------------ fused panel kernel
+// One launch per 64-column panel.  Every workgroup (4 wavefronts) holds in LDS the
+// 64 x 64 diagonal block (rows 0..63 of M) stacked on its OWN 64 panel rows (rows
+// 64..127) and runs a 16-blocked right-looking LDL^T on the 128 x 64 stack:
+//   (a) 16 x 16 diagonal tile: unblocked, rows in VGPRs of 16 lanes, v_readlane broadcasts
+//   (b) rows below the tile: X L_bb^T = A by substitution, one lane per row (16 VGPRs),
+//       L_bb broadcast from LDS; emits W = X (to LDS for (c), to the W workspace for the
+//       own rows) and L = X D^-1
+//   (c) remaining tiles to the right: M_tile -= W_ti L_tj^T with v_mfma_f64_16x16x4_f64
+// The diagonal block is factored redundantly by every workgroup (it is on the critical
+// path anyway and this removes one launch boundary per panel); workgroup 0 writes it
+// back together with D, 1/D, the zero-pivot flag and the negative-pivot count.
+// All loops over tiles are rolled (LDS offsets computed at run time): the code stays a
+// few KB, unlike a fully unrolled in-register 64 x 64 elimination, which is
+// instruction-fetch bound when launched cold.
+#define PNL_LD 66   // LDS row stride of M: conflict-free MFMA fragment reads, 16 B rows
+#define PNL_WLD 18
+
 template <int NB>
-__global__ __launch_bounds__(64) void k_ldlt_trsm(double *__restrict__ K, int64_t ldk,
-                                                   double *__restrict__ W, int N, int nrows,
-                                                   int c0, const double *__restrict__ dinv) {
-  __shared__ double Ls[NB][NB];
-  __shared__ double dis[NB];
-  const int tid = threadIdx.x;
+__global__ __launch_bounds__(256) void k_ldlt_panel(double *__restrict__ K, int64_t ldk,
+                                                    double *__restrict__ W, int64_t ldw, int wofs,
+                                                    int N, int nrows, int c0,
+                                                    double *__restrict__ dvec,
+                                                    double *__restrict__ dinv,
+                                                    int *__restrict__ flags, int skip) {
+  static_assert(NB == 64, "panel kernel is written for 64-column panels");
+  __shared__ __attribute__((aligned(16))) double M[128][PNL_LD];
+  __shared__ __attribute__((aligned(16))) double Wt[128][PNL_WLD];
+  __shared__ double dD[NB], dI[NB];
+  __shared__ int s_bad;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
   const int nb = min(NB, N - c0);
-  for (int idx = tid; idx < NB * NB; idx += 64) {
-    const int i = idx / NB, j = idx % NB;
-    Ls[i][j] = (i < nb && j < i) ? K[(int64_t)(c0 + i) * ldk + c0 + j] : 0.0;
+  const int rbase = c0 + nb + blockIdx.x * 64;  // first own row (global)
+  if (tid == 0) s_bad = 0;
+
+  // ---- load: diag block (identity outside the valid lower triangle) + own rows
+  for (int p = tid; p < 128 * 32; p += 256) {
+    const int row = p >> 5, c2 = (p & 31) * 2;
+    double2_t v = (double2_t){0.0, 0.0};
+    if (row < 64) {
+      if (row < nb) {
+        const double *src = K + (int64_t)(c0 + row) * ldk + c0 + c2;
+        if (c2 + 1 <= row) v = *reinterpret_cast<const double2_t *>(src);
+        else if (c2 <= row) v.x = src[0];
+      }
+      if (row >= nb) {  // identity padding keeps the elimination well defined
+        if (c2 == row) v.x = 1.0;
+        if (c2 + 1 == row) v.y = 1.0;
+      }
+    } else {
+      const int r = rbase + row - 64;
+      if (r < nrows) {
+        const double *src = K + (int64_t)r * ldk + c0 + c2;
+        if (c2 + 1 < nb) v = *reinterpret_cast<const double2_t *>(src);
+        else if (c2 < nb) v.x = src[0];
+      }
+    }
+    *reinterpret_cast<double2_t *>(&M[row][c2]) = v;
   }
-  dis[tid] = (tid < nb) ? dinv[c0 + tid] : 0.0;
   __syncthreads();
-  // rows below the block start at c0 + nb (a partial last block is followed only by
-  // carried right-hand-side rows)
-  const int r = c0 + nb + blockIdx.x * 64 + tid;
-  if (r >= nrows) return;
-  double *rowp = K + (int64_t)r * ldk + c0;
-  double x[NB];
-  if (nb == NB) {
+
+  for (int sb = 0; sb < 4; ++sb) {
+    const int cb = sb * 16;
+    // ---- (a) factor the 16 x 16 diagonal tile: wavefront 0, lane (l & 15) <-> row
+    if (wave == 0 && !(skip & 1)) {
+      double a[16];
 #pragma unroll
-    for (int j = 0; j < NB; j += 2) {
-      const double2_t v = *reinterpret_cast<const double2_t *>(rowp + j);
-      x[j] = v.x;
-      x[j + 1] = v.y;
+      for (int k = 0; k < 16; ++k) a[k] = M[cb + l15][cb + k];
+      double d_mine = 1.0, di_mine = 1.0;
+      int bad_any = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const double d = lane_bcast(a[j], j);
+        const bool bad = (d == 0.0) || !(fabs(d) <= 1.79e308);
+        const double di = bad ? 0.0 : 1.0 / d;
+        bad_any |= (bad && (cb + j) < nb) ? 1 : 0;
+        if (l15 == j) {
+          d_mine = d;
+          di_mine = di;
+        }
+        const double l = a[j] * di;
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) a[k] = fma(-l, lane_bcast(a[j], k), a[k]);
+        a[j] = l;
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (k < lane) M[cb + lane][cb + k] = a[k];
+        M[cb + lane][cb + lane] = d_mine;
+        dD[cb + lane] = d_mine;
+        dI[cb + lane] = di_mine;
+        if (lane == 0 && bad_any) s_bad = 1;
+      }
     }
-  } else {
+    __syncthreads();
+    // ---- (b) rows below the tile: substitution, one lane per row (wavefronts 0 and 1)
+    if (wave < 2 && !(skip & 2)) {
+      const int row = cb + 16 + wave * 64 + lane;
+      if (row < 128) {
+        double x[16];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) x[j] = (j < nb) ? rowp[j] : 0.0;
-  }
+        for (int k = 0; k < 16; k += 2) {
+          const double2_t v = *reinterpret_cast<const double2_t *>(&M[row][cb + k]);
+          x[k] = v.x;
+          x[k + 1] = v.y;
+        }
 #pragma unroll
-  for (int j = 1; j < NB; ++j) {
-    double s = x[j];
+        for (int t = 0; t < 15; ++t) {
+          const double xt = x[t];
 #pragma unroll
-    for (int t = 0; t < j; ++t) s = fma(-x[t], Ls[j][t], s);
-    x[j] = s;
-  }
-  double *wp = W + (int64_t)r * NB;
+          for (int j = t + 1; j < 16; ++j) x[j] = fma(-xt, M[cb + j][cb + t], x[j]);
+        }
 #pragma unroll
-  for (int j = 0; j < NB; j += 2) {
-    double2_t w;
-    w.x = x[j];
-    w.y = x[j + 1];
-    *reinterpret_cast<double2_t *>(wp + j) = w;
-  }
-  if (nb == NB) {
+        for (int k = 0; k < 16; k += 2) {
+          double2_t w, l;
+          w.x = x[k];
+          w.y = x[k + 1];
+          l.x = x[k] * dI[cb + k];
+          l.y = x[k + 1] * dI[cb + k + 1];
+          *reinterpret_cast<double2_t *>(&Wt[row][k]) = w;
+          *reinterpret_cast<double2_t *>(&M[row][cb + k]) = l;
+        }
+        if (row >= 64) {
+          const int r = rbase + row - 64;
+          if (r < nrows) {
+            double *wp = W + (int64_t)r * ldw + wofs + cb;
 #pragma unroll
-    for (int j = 0; j < NB; j += 2) {
-      double2_t l;
-      l.x = x[j] * dis[j];
-      l.y = x[j + 1] * dis[j + 1];
-      *reinterpret_cast<double2_t *>(rowp + j) = l;
+            for (int k = 0; k < 16; k += 2) {
+              double2_t w;
+              w.x = x[k];
+              w.y = x[k + 1];
+              *reinterpret_cast<double2_t *>(wp + k) = w;
+            }
+          }
+        }
+      }
     }
-  } else {
+    __syncthreads();
+    // ---- (c) tiles to the right: M[ti][tj] -= W[ti] L[tj]^T, tj in (sb, 3], ti in [tj, 7]
+    if (sb < 3 && !(skip & 4)) {
+      int total = 0;
+      for (int tj = sb + 1; tj < 4; ++tj) total += 8 - tj;
+      for (int e0 = wave; e0 < total; e0 += 4) {
+        int e = e0, tj = sb + 1;
+        while (e >= 8 - tj) {
+          e -= 8 - tj;
+          ++tj;
+        }
+        const int ti = tj + e;
+        double4_t acc;
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
-      if (j < nb) rowp[j] = x[j] * dis[j];
+        for (int r = 0; r < 4; ++r) acc[r] = M[ti * 16 + l4 + 4 * r][tj * 16 + l15];
+#pragma unroll
+        for (int ks = 0; ks < 16; ks += 4) {
+          const double av = -Wt[ti * 16 + l15][ks + l4];
+          const double bv = M[tj * 16 + l15][cb + ks + l4];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) M[ti * 16 + l4 + 4 * r][tj * 16 + l15] = acc[r];
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- write back: own rows (L), and by workgroup 0 the factored diagonal block
+  for (int p = tid; p < 64 * 32; p += 256) {
+    const int row = p >> 5, c2 = (p & 31) * 2;
+    const int r = rbase + row;
+    if (r < nrows) {
+      const double2_t v = *reinterpret_cast<const double2_t *>(&M[64 + row][c2]);
+      double *dst = K + (int64_t)r * ldk + c0 + c2;
+      if (c2 + 1 < nb) *reinterpret_cast<double2_t *>(dst) = v;
+      else if (c2 < nb) dst[0] = v.x;
+    }
+  }
+  if (blockIdx.x == 0) {
+    for (int p = tid; p < 64 * 64; p += 256) {
+      const int row = p >> 6, c = p & 63;
+      if (row < nb && c <= row) K[(int64_t)(c0 + row) * ldk + c0 + c] = M[row][c];
+    }
+    if (tid < nb) {
+      dvec[c0 + tid] = dD[tid];
+      dinv[c0 + tid] = dI[tid];
+    }
+    if (wave == 0) {
+      const unsigned long long negs = __ballot(lane < nb && dD[lane] < 0.0);
+      if (lane == 0) {
+        if (s_bad) atomicOr(&flags[0], 1);
+        const int neg = __popcll(negs);
+        if (neg) atomicAdd(&flags[1], neg);
+      }
+    }
   }
 }
 
@@ -145,9 +232,11 @@ __global__ __launch_bounds__(64) void k_ldlt_trsm(double *__restrict__ K, int64_
 // (rows >= N are carried right-hand sides: every column < N is "below" them).
 // 128 x 128 tile per workgroup, 4 wavefronts as 2 x 2, each 64 x 64 = 4 x 4 MFMA tiles
 // of v_mfma_f64_16x16x4_f64 (A: lane l holds A[l&15][l>>4], B: B[l>>4][l&15],
-// C/D: row = (l>>4) + 4*reg, col = l&15).  K-chunks of 16 staged through LDS with the
-// next chunk prefetched into registers; LDS rows padded to 18 doubles (bank-conflict
-// free ds_read_b64 for the fragment pattern, 16-byte aligned ds_write_b128).
+// C/D: row = (l>>4) + 4*reg, col = l&15).  The accumulators START as the C tile (all 64
+// loads in flight at once, hidden behind the first operand fetch) and -W is staged, so
+// the epilogue is store-only.  K-chunks of 16 go through LDS with the next chunk
+// prefetched into registers; LDS rows padded to 18 doubles (conflict-free ds_read_b64
+// for the fragment pattern, 16-byte aligned ds_write_b128).
 #define UPD_BM 128
 #define UPD_BK 16
 #define UPD_LDS 18
@@ -167,11 +256,23 @@ __global__ __launch_bounds__(256, 2) void k_ldlt_update(double *__restrict__ K, 
   const int wr = wave >> 1, wc = wave & 1;
   const int l15 = lane & 15, l4 = lane >> 4;
 
+  // accumulators <- C tile (entries above the diagonal / outside the region are never
+  // stored back; whatever they hold stays confined to its own accumulator element)
   double4_t acc[4][4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int nj = 0; nj < 4; ++nj) {
+      const int j = j0 + wc * 64 + nj * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + wr * 64 + mi * 16 + l4 + 4 * r;
+        double v = 0.0;
+        if (i < nrows && j < colEnd && j <= i) v = K[(int64_t)i * ldk + j];
+        acc[mi][nj][r] = v;
+      }
+    }
+  }
 
   // staging map: piece p = q*256 + tid -> row p>>3, two doubles at column (p&7)*2
   double2_t pa[4], pb[4];
@@ -185,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void k_ldlt_update(double *__restrict__ K, 
       if (gi < nrows) va = *reinterpret_cast<const double2_t *>(W + (int64_t)gi * ldw + kk + kofs);
       if (gj < colEnd)
         vb = *reinterpret_cast<const double2_t *>(K + (int64_t)gj * ldk + kc0 + kk + kofs);
-      pa[q] = va;
+      pa[q] = -va;
       pb[q] = vb;
     }
   };
@@ -221,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void k_ldlt_update(double *__restrict__ K, 
     }
   }
 
-  // epilogue: C -= acc on the lower triangle of the region
+  // epilogue: store-only, lower triangle of the region
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
@@ -230,10 +331,7 @@ __global__ __launch_bounds__(256, 2) void k_ldlt_update(double *__restrict__ K, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = i0 + wr * 64 + mi * 16 + l4 + 4 * r;
-        if (i < nrows && j < colEnd && j <= i) {
-          double *cp = K + (int64_t)i * ldk + j;
-          *cp = *cp - acc[mi][nj][r];
-        }
+        if (i < nrows && j < colEnd && j <= i) K[(int64_t)i * ldk + j] = acc[mi][nj][r];
       }
     }
   }
@@ -241,9 +339,9 @@ __global__ __launch_bounds__(256, 2) void k_ldlt_update(double *__restrict__ K, 
 
 // ------------------------------------------------------------------ triangular solves
 // One launch per 64-row block.  Every workgroup (one wavefront) redundantly solves the
-// 64 x 64 diagonal system with wavefront shuffles, then updates its own 64 entries of the
-// work vector; workgroup 0 also publishes the block of the solution.  `z` is the work
-// vector (updated in place below/above the block), `x` receives the solution.
+// 64 x 64 diagonal system (lane broadcasts through v_readlane), then updates its own 64
+// entries of the work vector; workgroup 0 also publishes the block of the solution.
+// `z` is the work vector (updated in place below/above the block), `x` the solution.
 template <int NB>
 __global__ __launch_bounds__(64) void k_trsv_fwd(const double *__restrict__ K, int64_t ldk,
                                                   double *__restrict__ z, double *__restrict__ x,
@@ -255,26 +353,34 @@ __global__ __launch_bounds__(64) void k_trsv_fwd(const double *__restrict__ K, i
   const double *lp = K + (int64_t)(c0 + lane) * ldk + c0;
 #pragma unroll
   for (int j = 0; j < NB; ++j) lrow[j] = (lane < nb && j < lane) ? lp[j] : 0.0;
-  double xv = (lane < nb) ? z[c0 + lane] : 0.0;
-#pragma unroll
-  for (int j = 0; j < NB - 1; ++j) {
-    const double xj = __shfl(xv, j);
-    xv = fma(-lrow[j], xj, xv);  // lrow[j] == 0 for lanes <= j
-  }
-  if (blockIdx.x == 0 && lane < nb) x[c0 + lane] = xv;
-  // update rows below the block
+  // this lane's row below the block (independent of the solve: issue the loads now)
   const int r = c0 + NB + blockIdx.x * 64 + lane;
   const bool live = r < N;
   const double *rp = K + (int64_t)(live ? r : 0) * ldk + c0;
-  double s = live ? z[r] : 0.0;
+  double urow[NB];
 #pragma unroll
   for (int j = 0; j < NB; j += 2) {
     double2_t v = (double2_t){0.0, 0.0};
     if (live) v = *reinterpret_cast<const double2_t *>(rp + j);
-    s = fma(-v.x, __shfl(xv, j), s);
-    s = fma(-v.y, __shfl(xv, j + 1), s);
+    urow[j] = v.x;
+    urow[j + 1] = v.y;
   }
-  if (live) z[r] = s;
+  double s0 = live ? z[r] : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  double xv = (lane < nb) ? z[c0 + lane] : 0.0;
+#pragma unroll
+  for (int j = 0; j < NB - 1; ++j) {
+    const double xj = lane_bcast(xv, j);
+    xv = fma(-lrow[j], xj, xv);  // lrow[j] == 0 for lanes <= j
+  }
+  if (blockIdx.x == 0 && lane < nb) x[c0 + lane] = xv;
+#pragma unroll
+  for (int j = 0; j < NB; j += 4) {
+    s0 = fma(-urow[j], lane_bcast(xv, j), s0);
+    s1 = fma(-urow[j + 1], lane_bcast(xv, j + 1), s1);
+    s2 = fma(-urow[j + 2], lane_bcast(xv, j + 2), s2);
+    s3 = fma(-urow[j + 3], lane_bcast(xv, j + 3), s3);
+  }
+  if (live) z[r] = (s0 + s1) + (s2 + s3);
 }
 
 // Backward: L^T s = w.  Block solved with the transposed diagonal block; columns to the
@@ -289,26 +395,29 @@ __global__ __launch_bounds__(64) void k_trsv_bwd(const double *__restrict__ K, i
 #pragma unroll
   for (int j = 0; j < NB; ++j)
     lcol[j] = (j < nb && j > lane) ? K[(int64_t)(c0 + j) * ldk + c0 + lane] : 0.0;
+  // column t of the block row, to the left of the block (loads independent of the solve)
+  const int t = blockIdx.x * 64 + lane;
+  const bool live = (c0 > 0) && t < c0;
+  const double *cp = K + (int64_t)c0 * ldk + (live ? t : 0);
+  double ucol[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) ucol[j] = (live && j < nb) ? cp[(int64_t)j * ldk] : 0.0;
+  double s0 = live ? z[t] : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   double xv = (lane < nb) ? z[c0 + lane] : 0.0;
 #pragma unroll
   for (int j = NB - 1; j > 0; --j) {
-    const double xj = __shfl(xv, j);
+    const double xj = lane_bcast(xv, j);
     xv = fma(-lcol[j], xj, xv);  // lcol[j] == 0 for lanes >= j
   }
   if (blockIdx.x == 0 && lane < nb) x[c0 + lane] = xv;
-  // update entries left of the block: z[t] -= sum_j L[c0 + j][t] * x_j
-  const int t = blockIdx.x * 64 + lane;
-  if (c0 == 0) return;
-  const bool live = t < c0;
-  double s = live ? z[t] : 0.0;
-  const double *cp = K + (int64_t)c0 * ldk + (live ? t : 0);
-#pragma unroll 8
-  for (int j = 0; j < NB; ++j) {
-    const double xj = __shfl(xv, j);
-    const double l = (live && j < nb) ? cp[(int64_t)j * ldk] : 0.0;
-    s = fma(-l, xj, s);
+#pragma unroll
+  for (int j = 0; j < NB; j += 4) {
+    s0 = fma(-ucol[j], lane_bcast(xv, j), s0);
+    s1 = fma(-ucol[j + 1], lane_bcast(xv, j + 1), s1);
+    s2 = fma(-ucol[j + 2], lane_bcast(xv, j + 2), s2);
+    s3 = fma(-ucol[j + 3], lane_bcast(xv, j + 3), s3);
   }
-  if (live) z[t] = s;
+  if (live) z[t] = (s0 + s1) + (s2 + s3);
 }
 
 __global__ void k_vec_scale(double *__restrict__ z, const double *__restrict__ dinv, int N) {
@@ -381,12 +490,11 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
     (void)hipEventRecord(p->factor_span.first, s);
   }
   for (int c0 = 0; c0 < N; c0 += PGF_NB) {
-    hipLaunchKernelGGL(k_ldlt_diag<PGF_NB>, dim3(1), dim3(256), 0, s, f.K, f.ldk, N, c0, f.dvec,
-                       f.dinv, f.flags);
     const int below = nrows - std::min(c0 + PGF_NB, N);
+    hipLaunchKernelGGL(k_ldlt_panel<PGF_NB>, dim3(std::max(1, (below + 63) / 64)), dim3(256), 0, s,
+                       f.K, f.ldk, f.W, (int64_t)PGF_NB, 0, N, nrows, c0, f.dvec, f.dinv, f.flags,
+                       getenv("PGF_SKIP") ? atoi(getenv("PGF_SKIP")) : 0);
     if (below > 0) {
-      hipLaunchKernelGGL(k_ldlt_trsm<PGF_NB>, dim3((below + 63) / 64), dim3(64), 0, s, f.K, f.ldk,
-                         f.W, N, nrows, c0, f.dinv);
       const int c1 = c0 + PGF_NB;
       if (c1 < N) {
         const int tr = (nrows - c1 + UPD_BM - 1) / UPD_BM;
