@@ -29,6 +29,17 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
+// 1 / d to within an ulp or two: v_rcp_f64 seed + two Newton steps (5 dependent ops
+// instead of the ~12 of an IEEE-correct division; the pivots only enter through
+// products, which the 1e-10 iterate tolerance covers with 5 digits to spare)
+__device__ __forceinline__ double fast_recip(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-d, r, 1.0);
+  return fma(r, e, r);
+}
+
 // ------------------------------------------------------------------ fused panel kernel
 // One launch per 64-column panel.  Every workgroup (4 wavefronts) holds in LDS the
 // 64 x 64 diagonal block (rows 0..63 of M) stacked on its OWN 64 panel rows (rows
@@ -65,29 +76,40 @@ __global__ __launch_bounds__(256) void k_ldlt_panel(double *__restrict__ K, int6
   const int rbase = c0 + nb + blockIdx.x * 64;  // first own row (global)
   if (tid == 0) s_bad = 0;
 
-  // ---- load: diag block (identity outside the valid lower triangle) + own rows
-  for (int p = tid; p < 128 * 32; p += 256) {
-    const int row = p >> 5, c2 = (p & 31) * 2;
-    double2_t v = (double2_t){0.0, 0.0};
-    if (row < 64) {
-      if (row < nb) {
-        const double *src = K + (int64_t)(c0 + row) * ldk + c0 + c2;
-        if (c2 + 1 <= row) v = *reinterpret_cast<const double2_t *>(src);
-        else if (c2 <= row) v.x = src[0];
+  // ---- load: diag block (identity outside the valid lower triangle) + own rows.
+  // All 16 global loads of a lane are issued before the first LDS store (one memory
+  // latency instead of sixteen).
+  {
+    double2_t v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int p = q * 256 + tid;
+      const int row = p >> 5, c2 = (p & 31) * 2;
+      double2_t t = (double2_t){0.0, 0.0};
+      if (row < 64) {
+        if (row < nb) {
+          const double *src = K + (int64_t)(c0 + row) * ldk + c0 + c2;
+          if (c2 + 1 <= row) t = *reinterpret_cast<const double2_t *>(src);
+          else if (c2 <= row) t.x = src[0];
+        } else {  // identity padding keeps the elimination well defined
+          if (c2 == row) t.x = 1.0;
+          if (c2 + 1 == row) t.y = 1.0;
+        }
+      } else {
+        const int r = rbase + row - 64;
+        if (r < nrows) {
+          const double *src = K + (int64_t)r * ldk + c0 + c2;
+          if (c2 + 1 < nb) t = *reinterpret_cast<const double2_t *>(src);
+          else if (c2 < nb) t.x = src[0];
+        }
       }
-      if (row >= nb) {  // identity padding keeps the elimination well defined
-        if (c2 == row) v.x = 1.0;
-        if (c2 + 1 == row) v.y = 1.0;
-      }
-    } else {
-      const int r = rbase + row - 64;
-      if (r < nrows) {
-        const double *src = K + (int64_t)r * ldk + c0 + c2;
-        if (c2 + 1 < nb) v = *reinterpret_cast<const double2_t *>(src);
-        else if (c2 < nb) v.x = src[0];
-      }
+      v[q] = t;
     }
-    *reinterpret_cast<double2_t *>(&M[row][c2]) = v;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int p = q * 256 + tid;
+      *reinterpret_cast<double2_t *>(&M[p >> 5][(p & 31) * 2]) = v[q];
+    }
   }
   __syncthreads();
 
@@ -104,7 +126,7 @@ __global__ __launch_bounds__(256) void k_ldlt_panel(double *__restrict__ K, int6
       for (int j = 0; j < 16; ++j) {
         const double d = lane_bcast(a[j], j);
         const bool bad = (d == 0.0) || !(fabs(d) <= 1.79e308);
-        const double di = bad ? 0.0 : 1.0 / d;
+        const double di = bad ? 0.0 : fast_recip(d);
         bad_any |= (bad && (cb + j) < nb) ? 1 : 0;
         if (l15 == j) {
           d_mine = d;
