@@ -37,6 +37,8 @@ struct DenseLdlt {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // look-ahead stream (trailing update)
   hipEvent_t ev_panel = nullptr, ev_update = nullptr;
+  int OB = 128;             // outer block width (K-depth of the bulk trailing update)
+  size_t wstride = 0;       // doubles per W buffer (two buffers)
   int N = 0;
   bool factored = false;
   int n_neg = 0;

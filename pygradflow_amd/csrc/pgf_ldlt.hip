@@ -467,7 +467,16 @@ hipError_t ldlt_alloc(DenseLdlt &f, int Nmax, hipStream_t stream) {
   hipError_t e;
   const size_t rows = (size_t)Nmax + 1 + PGF_NB;
   if ((e = hipMalloc(&f.K, rows * f.ldk * sizeof(double))) != hipSuccess) return e;
-  if ((e = hipMalloc(&f.W, rows * PGF_NB * sizeof(double))) != hipSuccess) return e;
+  f.OB = 128;
+  if (const char *ob = getenv("PGF_OB")) {
+    const int v = atoi(ob);
+    if (v == 64 || v == 128 || v == 192 || v == 256) f.OB = v;
+  }
+  f.wstride = rows * (size_t)f.OB;
+  if ((e = hipMalloc(&f.W, 2 * f.wstride * sizeof(double))) != hipSuccess) return e;
+  if ((e = hipStreamCreateWithFlags(&f.stream2, hipStreamNonBlocking)) != hipSuccess) return e;
+  if ((e = hipEventCreateWithFlags(&f.ev_panel, hipEventDisableTiming)) != hipSuccess) return e;
+  if ((e = hipEventCreateWithFlags(&f.ev_update, hipEventDisableTiming)) != hipSuccess) return e;
   if ((e = hipMalloc(&f.dvec, rows * sizeof(double))) != hipSuccess) return e;
   if ((e = hipMalloc(&f.dinv, rows * sizeof(double))) != hipSuccess) return e;
   if ((e = hipMalloc(&f.zwork, rows * sizeof(double))) != hipSuccess) return e;
@@ -484,6 +493,9 @@ void ldlt_free(DenseLdlt &f) {
   if (f.zwork) (void)hipFree(f.zwork);
   if (f.flags) (void)hipFree(f.flags);
   if (f.h_flags) (void)hipHostFree(f.h_flags);
+  if (f.ev_panel) (void)hipEventDestroy(f.ev_panel);
+  if (f.ev_update) (void)hipEventDestroy(f.ev_update);
+  if (f.stream2) (void)hipStreamDestroy(f.stream2);
   f = DenseLdlt();
 }
 
@@ -498,50 +510,96 @@ static hipEvent_t prof_event(PgfProfile *p) {
   return e;
 }
 
+// Launch one trailing-update region (see k_ldlt_update) on stream `s`, optionally
+// bracketed by profiling events.
+static void launch_update(DenseLdlt &f, hipStream_t s, const double *Wp, int64_t ldw, int N,
+                          int nrows, int row0, int col0, int colEnd, int kc0, int KB,
+                          PgfProfile *p) {
+  if (row0 >= nrows || col0 >= colEnd) return;
+  const int tr = (nrows - row0 + UPD_BM - 1) / UPD_BM;
+  const int tc = (colEnd - col0 + UPD_BM - 1) / UPD_BM;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (p) {
+    e0 = prof_event(p);
+    e1 = prof_event(p);
+    (void)hipEventRecord(e0, s);
+  }
+  hipLaunchKernelGGL(k_ldlt_update, dim3(tc, tr), dim3(256), 0, s, f.K, f.ldk, Wp, ldw, N, nrows,
+                     row0, col0, colEnd, kc0, KB);
+  if (p) {
+    (void)hipEventRecord(e1, s);
+    p->update_spans.emplace_back(e0, e1);
+    // algorithmic flops: entries (i, j) of the region with j <= i, 2*KB flops each
+    double cnt = 0.0;
+    const double lo = col0, hi = colEnd;  // columns [lo, hi)
+    // rows i in [row0, nrows): columns j in [lo, min(hi, i + 1))
+    for (int i = row0; i < nrows; i += 1) {
+      const double top = (i + 1 < hi) ? (double)(i + 1) : hi;
+      if (top > lo) cnt += top - lo;
+    }
+    p->update_flops.push_back(2.0 * cnt * KB);
+  }
+}
+
+// Two-level right-looking factorisation with a depth-1 look-ahead over two streams.
+//   outer block (f.OB columns):  inner 64-column panels  [stream A]
+//                                inner updates restricted to the outer block, K = 64 [A]
+//   bulk update with K = OB:     next outer block's columns [A]  ||  the rest [B]
+// W (= L D of the current outer block, OB columns wide) is double buffered because the
+// bulk update on stream B still reads it while stream A factors the next outer block.
 hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
   f.N = N;
   f.factored = false;
-  hipStream_t s = f.stream;
-  hipError_t e = hipMemsetAsync(f.flags, 0, 4 * sizeof(int), s);
+  hipStream_t sA = f.stream, sB = f.stream2;
+  hipError_t e = hipMemsetAsync(f.flags, 0, 4 * sizeof(int), sA);
   if (e != hipSuccess) return e;
   PgfProfile *p = (f.prof && f.prof->enabled) ? f.prof : nullptr;
   if (p) {
+    if (p->factor_open) {  // an unread span: fold it into the pool
+      p->pool.push_back(p->factor_span.first);
+      p->pool.push_back(p->factor_span.second);
+    }
     p->factor_span.first = prof_event(p);
     p->factor_span.second = prof_event(p);
     p->factor_open = true;
-    (void)hipEventRecord(p->factor_span.first, s);
+    (void)hipEventRecord(p->factor_span.first, sA);
   }
-  for (int c0 = 0; c0 < N; c0 += PGF_NB) {
-    const int below = nrows - std::min(c0 + PGF_NB, N);
-    hipLaunchKernelGGL(k_ldlt_panel<PGF_NB>, dim3(std::max(1, (below + 63) / 64)), dim3(256), 0, s,
-                       f.K, f.ldk, f.W, (int64_t)PGF_NB, 0, N, nrows, c0, f.dvec, f.dinv, f.flags,
-                       getenv("PGF_SKIP") ? atoi(getenv("PGF_SKIP")) : 0);
-    if (below > 0) {
+  const int OB = f.OB;
+  const int skip = getenv("PGF_SKIP") ? atoi(getenv("PGF_SKIP")) : 0;
+  bool b_pending = false;
+  int buf = 0;
+  // stream B must not start before everything already queued on A (assembly, rhs row)
+  (void)hipEventRecord(f.ev_panel, sA);
+  (void)hipStreamWaitEvent(sB, f.ev_panel, 0);
+  for (int ob0 = 0; ob0 < N; ob0 += OB, buf ^= 1) {
+    const int obEnd = std::min(ob0 + OB, N);
+    double *Wb = f.W + (size_t)buf * f.wstride;
+    for (int c0 = ob0; c0 < obEnd; c0 += PGF_NB) {
+      const int below = nrows - std::min(c0 + PGF_NB, N);
+      hipLaunchKernelGGL(k_ldlt_panel<PGF_NB>, dim3(std::max(1, (below + 63) / 64)), dim3(256), 0,
+                         sA, f.K, f.ldk, Wb, (int64_t)OB, c0 - ob0, N, nrows, c0, f.dvec, f.dinv,
+                         f.flags, skip);
       const int c1 = c0 + PGF_NB;
-      if (c1 < N) {
-        const int tr = (nrows - c1 + UPD_BM - 1) / UPD_BM;
-        const int tc = (N - c1 + UPD_BM - 1) / UPD_BM;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (p) {
-          e0 = prof_event(p);
-          e1 = prof_event(p);
-          (void)hipEventRecord(e0, s);
-        }
-        hipLaunchKernelGGL(k_ldlt_update, dim3(tc, tr), dim3(256), 0, s, f.K, f.ldk, f.W,
-                           (int64_t)PGF_NB, N, nrows, c1, c1, N, c0, PGF_NB);
-        if (p) {
-          (void)hipEventRecord(e1, s);
-          p->update_spans.emplace_back(e0, e1);
-          const double t = (double)(N - c1);
-          // algorithmic flops of this launch: lower triangle of the trailing block
-          // (+ carried rows), 2 flops per multiply-add, K-depth NB
-          p->update_flops.push_back((t * (t + 1.0) + 2.0 * t * (nrows - N)) * PGF_NB);
-        }
+      if (c1 < obEnd)  // inner update: the rest of this outer block's columns, K = 64
+        launch_update(f, sA, Wb + (c0 - ob0), OB, N, nrows, c1, c1, obEnd, c0, PGF_NB, p);
+    }
+    if (obEnd < N) {
+      const int KB = obEnd - ob0;  // == OB here (only the last outer block may be short)
+      const int nextEnd = std::min(obEnd + OB, N);
+      if (b_pending) (void)hipStreamWaitEvent(sA, f.ev_update, 0);  // RMW order on next block
+      launch_update(f, sA, Wb, OB, N, nrows, obEnd, obEnd, nextEnd, ob0, KB, p);
+      if (nextEnd < N) {
+        (void)hipEventRecord(f.ev_panel, sA);
+        (void)hipStreamWaitEvent(sB, f.ev_panel, 0);
+        launch_update(f, sB, Wb, OB, N, nrows, nextEnd, nextEnd, N, ob0, KB, p);
+        (void)hipEventRecord(f.ev_update, sB);
+        b_pending = true;
       }
     }
   }
-  if (p) (void)hipEventRecord(p->factor_span.second, s);
-  e = hipMemcpyAsync(f.h_flags, f.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s);
+  if (b_pending) (void)hipStreamWaitEvent(sA, f.ev_update, 0);
+  if (p) (void)hipEventRecord(p->factor_span.second, sA);
+  e = hipMemcpyAsync(f.h_flags, f.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, sA);
   if (e != hipSuccess) return e;
   return hipGetLastError();
 }
