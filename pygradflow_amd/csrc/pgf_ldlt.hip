@@ -550,7 +550,7 @@ static void launch_update(DenseLdlt &f, hipStream_t s, const double *Wp, int64_t
 hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
   f.N = N;
   f.factored = false;
-  hipStream_t sA = f.stream, sB = f.stream2;
+  hipStream_t sA = f.stream, sB = getenv("PGF_NOLOOKAHEAD") ? f.stream : f.stream2;
   hipError_t e = hipMemsetAsync(f.flags, 0, 4 * sizeof(int), sA);
   if (e != hipSuccess) return e;
   PgfProfile *p = (f.prof && f.prof->enabled) ? f.prof : nullptr;
