@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void k_ldlt_update(double *__restrict__ K, 
       if (gi < nrows) va = *reinterpret_cast<const double2_t *>(W + (int64_t)gi * ldw + kk + kofs);
       if (gj < colEnd)
         vb = *reinterpret_cast<const double2_t *>(K + (int64_t)gj * ldk + kc0 + kk + kofs);
-      pa[q] = -va;
+      pa[q] = va;
       pb[q] = vb;
     }
   };
@@ -317,7 +317,8 @@ __global__ __launch_bounds__(256, 2) void k_ldlt_update(double *__restrict__ K, 
     for (int q = 0; q < 4; ++q) {
       const int p = q * 256 + tid;
       const int row = p >> 3, kofs = (p & 7) * 2;
-      *reinterpret_cast<double2_t *>(&As[row][kofs]) = pa[q];
+      *reinterpret_cast<double2_t *>(&As[row][kofs]) = -pa[q];  // negate here, not at the
+      // fetch: touching the loaded value there would wait for the prefetch immediately
       *reinterpret_cast<double2_t *>(&Bs[row][kofs]) = pb[q];
     }
   };
