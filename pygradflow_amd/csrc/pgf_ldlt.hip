@@ -263,15 +263,22 @@ __global__ __launch_bounds__(256) void k_ldlt_panel(double *__restrict__ K, int6
 #define UPD_BK 16
 #define UPD_LDS 18
 
+// BT = tile edge (128: bulk regions, 64: narrow regions such as the inner updates of an
+// outer block, where 128-wide tiles would leave most CUs idle); 4 wavefronts as 2 x 2,
+// each (BT/2) x (BT/2) = TT x TT MFMA tiles.
+template <int BT>
 __global__ __launch_bounds__(256, 2) void k_ldlt_update(double *__restrict__ K, int64_t ldk,
                                                         const double *__restrict__ W,
                                                         int64_t ldw, int N, int nrows, int row0,
                                                         int col0, int colEnd, int kc0, int KB) {
-  const int i0 = row0 + blockIdx.y * UPD_BM;
-  const int j0 = col0 + blockIdx.x * UPD_BM;
-  if (j0 > i0 + UPD_BM - 1) return;  // tile entirely above the diagonal
-  __shared__ __attribute__((aligned(16))) double As[UPD_BM][UPD_LDS];
-  __shared__ __attribute__((aligned(16))) double Bs[UPD_BM][UPD_LDS];
+  constexpr int TT = BT / 32;          // MFMA tiles per wavefront and dimension
+  constexpr int WT = BT / 2;           // rows / columns per wavefront
+  constexpr int PIECES = BT * 8 / 256; // 16-byte staging pieces per lane and operand
+  const int i0 = row0 + blockIdx.y * BT;
+  const int j0 = col0 + blockIdx.x * BT;
+  if (j0 > i0 + BT - 1) return;  // tile entirely above the diagonal
+  __shared__ __attribute__((aligned(16))) double As[BT][UPD_LDS];
+  __shared__ __attribute__((aligned(16))) double Bs[BT][UPD_LDS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -280,15 +287,15 @@ __global__ __launch_bounds__(256, 2) void k_ldlt_update(double *__restrict__ K, 
 
   // accumulators <- C tile (entries above the diagonal / outside the region are never
   // stored back; whatever they hold stays confined to its own accumulator element)
-  double4_t acc[4][4];
+  double4_t acc[TT][TT];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
+  for (int mi = 0; mi < TT; ++mi) {
 #pragma unroll
-    for (int nj = 0; nj < 4; ++nj) {
-      const int j = j0 + wc * 64 + nj * 16 + l15;
+    for (int nj = 0; nj < TT; ++nj) {
+      const int j = j0 + wc * WT + nj * 16 + l15;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = i0 + wr * 64 + mi * 16 + l4 + 4 * r;
+        const int i = i0 + wr * WT + mi * 16 + l4 + 4 * r;
         double v = 0.0;
         if (i < nrows && j < colEnd && j <= i) v = K[(int64_t)i * ldk + j];
         acc[mi][nj][r] = v;
@@ -297,10 +304,10 @@ __global__ __launch_bounds__(256, 2) void k_ldlt_update(double *__restrict__ K, 
   }
 
   // staging map: piece p = q*256 + tid -> row p>>3, two doubles at column (p&7)*2
-  double2_t pa[4], pb[4];
+  double2_t pa[PIECES], pb[PIECES];
   auto fetch = [&](int kk) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < PIECES; ++q) {
       const int p = q * 256 + tid;
       const int row = p >> 3, kofs = (p & 7) * 2;
       const int gi = i0 + row, gj = j0 + row;
@@ -314,11 +321,12 @@ __global__ __launch_bounds__(256, 2) void k_ldlt_update(double *__restrict__ K, 
   };
   auto stage = [&]() {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < PIECES; ++q) {
       const int p = q * 256 + tid;
       const int row = p >> 3, kofs = (p & 7) * 2;
-      *reinterpret_cast<double2_t *>(&As[row][kofs]) = -pa[q];  // negate here, not at the
-      // fetch: touching the loaded value there would wait for the prefetch immediately
+      // negate here, not at the fetch: touching the loaded value there would make the
+      // wavefront wait for the prefetch before it starts the current chunk's MFMAs
+      *reinterpret_cast<double2_t *>(&As[row][kofs]) = -pa[q];
       *reinterpret_cast<double2_t *>(&Bs[row][kofs]) = pb[q];
     }
   };
@@ -331,29 +339,29 @@ __global__ __launch_bounds__(256, 2) void k_ldlt_update(double *__restrict__ K, 
     if (kk + UPD_BK < KB) fetch(kk + UPD_BK);
 #pragma unroll
     for (int ks = 0; ks < UPD_BK; ks += 4) {
-      double a[4], b[4];
+      double a[TT], b[TT];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        a[t] = As[wr * 64 + t * 16 + l15][ks + l4];
-        b[t] = Bs[wc * 64 + t * 16 + l15][ks + l4];
+      for (int t = 0; t < TT; ++t) {
+        a[t] = As[wr * WT + t * 16 + l15][ks + l4];
+        b[t] = Bs[wc * WT + t * 16 + l15][ks + l4];
       }
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < TT; ++mi)
 #pragma unroll
-        for (int nj = 0; nj < 4; ++nj)
+        for (int nj = 0; nj < TT; ++nj)
           acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
     }
   }
 
   // epilogue: store-only, lower triangle of the region
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
+  for (int mi = 0; mi < TT; ++mi) {
 #pragma unroll
-    for (int nj = 0; nj < 4; ++nj) {
-      const int j = j0 + wc * 64 + nj * 16 + l15;
+    for (int nj = 0; nj < TT; ++nj) {
+      const int j = j0 + wc * WT + nj * 16 + l15;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = i0 + wr * 64 + mi * 16 + l4 + 4 * r;
+        const int i = i0 + wr * WT + mi * 16 + l4 + 4 * r;
         if (i < nrows && j < colEnd && j <= i) K[(int64_t)i * ldk + j] = acc[mi][nj][r];
       }
     }
@@ -517,16 +525,24 @@ static void launch_update(DenseLdlt &f, hipStream_t s, const double *Wp, int64_t
                           int nrows, int row0, int col0, int colEnd, int kc0, int KB,
                           PgfProfile *p) {
   if (row0 >= nrows || col0 >= colEnd) return;
-  const int tr = (nrows - row0 + UPD_BM - 1) / UPD_BM;
-  const int tc = (colEnd - col0 + UPD_BM - 1) / UPD_BM;
+  // narrow regions (inner updates, next-block update) get 64 x 64 tiles: a 128-wide tile
+  // grid would occupy only ~40 of the 256 CUs
+  const bool narrow = (colEnd - col0) <= 256;
+  const int bt = narrow ? 64 : UPD_BM;
+  const int tr = (nrows - row0 + bt - 1) / bt;
+  const int tc = (colEnd - col0 + bt - 1) / bt;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (p) {
     e0 = prof_event(p);
     e1 = prof_event(p);
     (void)hipEventRecord(e0, s);
   }
-  hipLaunchKernelGGL(k_ldlt_update, dim3(tc, tr), dim3(256), 0, s, f.K, f.ldk, Wp, ldw, N, nrows,
-                     row0, col0, colEnd, kc0, KB);
+  if (narrow)
+    hipLaunchKernelGGL(k_ldlt_update<64>, dim3(tc, tr), dim3(256), 0, s, f.K, f.ldk, Wp, ldw, N,
+                       nrows, row0, col0, colEnd, kc0, KB);
+  else
+    hipLaunchKernelGGL(k_ldlt_update<128>, dim3(tc, tr), dim3(256), 0, s, f.K, f.ldk, Wp, ldw, N,
+                       nrows, row0, col0, colEnd, kc0, KB);
   if (p) {
     (void)hipEventRecord(e1, s);
     p->update_spans.emplace_back(e0, e1);
