@@ -504,6 +504,7 @@ void ldlt_free(DenseLdlt &f) {
   if (f.h_flags) (void)hipHostFree(f.h_flags);
   if (f.ev_panel) (void)hipEventDestroy(f.ev_panel);
   if (f.ev_update) (void)hipEventDestroy(f.ev_update);
+  for (hipEvent_t ev : f.ev_ring) (void)hipEventDestroy(ev);
   if (f.stream2) (void)hipStreamDestroy(f.stream2);
   f = DenseLdlt();
 }
@@ -585,6 +586,16 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
   const int skip = getenv("PGF_SKIP") ? atoi(getenv("PGF_SKIP")) : 0;
   bool b_pending = false;
   int buf = 0;
+  int evi = 0;
+  auto next_event = [&]() -> hipEvent_t {
+    if ((size_t)evi >= f.ev_ring.size()) {
+      hipEvent_t ev;
+      (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+      f.ev_ring.push_back(ev);
+    }
+    return f.ev_ring[evi++];
+  };
+  hipEvent_t ev_b_done = nullptr;
   // stream B must not start before everything already queued on A (assembly, rhs row)
   (void)hipEventRecord(f.ev_panel, sA);
   (void)hipStreamWaitEvent(sB, f.ev_panel, 0);
@@ -603,18 +614,20 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
     if (obEnd < N) {
       const int KB = obEnd - ob0;  // == OB here (only the last outer block may be short)
       const int nextEnd = std::min(obEnd + OB, N);
-      if (b_pending) (void)hipStreamWaitEvent(sA, f.ev_update, 0);  // RMW order on next block
+      if (b_pending) (void)hipStreamWaitEvent(sA, ev_b_done, 0);  // RMW order on next block
       launch_update(f, sA, Wb, OB, N, nrows, obEnd, obEnd, nextEnd, ob0, KB, p);
       if (nextEnd < N) {
-        (void)hipEventRecord(f.ev_panel, sA);
-        (void)hipStreamWaitEvent(sB, f.ev_panel, 0);
+        hipEvent_t ev_a = next_event();
+        (void)hipEventRecord(ev_a, sA);
+        (void)hipStreamWaitEvent(sB, ev_a, 0);
         launch_update(f, sB, Wb, OB, N, nrows, nextEnd, nextEnd, N, ob0, KB, p);
-        (void)hipEventRecord(f.ev_update, sB);
+        ev_b_done = next_event();
+        (void)hipEventRecord(ev_b_done, sB);
         b_pending = true;
       }
     }
   }
-  if (b_pending) (void)hipStreamWaitEvent(sA, f.ev_update, 0);
+  if (b_pending) (void)hipStreamWaitEvent(sA, ev_b_done, 0);
   if (p) (void)hipEventRecord(p->factor_span.second, sA);
   e = hipMemcpyAsync(f.h_flags, f.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, sA);
   if (e != hipSuccess) return e;
