@@ -584,6 +584,7 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
   }
   const int OB = f.OB;
   const int skip = getenv("PGF_SKIP") ? atoi(getenv("PGF_SKIP")) : 0;
+  const int la_dbg = getenv("PGF_LA_DEBUG") ? atoi(getenv("PGF_LA_DEBUG")) : 0;
   bool b_pending = false;
   int buf = 0;
   int evi = 0;
@@ -604,10 +605,14 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
     double *Wb = f.W + (size_t)buf * f.wstride;
     for (int c0 = ob0; c0 < obEnd; c0 += PGF_NB) {
       const int below = nrows - std::min(c0 + PGF_NB, N);
+      if (la_dbg == 1 && b_pending) (void)hipStreamWaitEvent(sA, ev_b_done, 0);
+      if (la_dbg == 4 && b_pending && c0 == ob0) (void)hipStreamWaitEvent(sA, ev_b_done, 0);
+      if (la_dbg == 5 && b_pending && c0 != ob0) (void)hipStreamWaitEvent(sA, ev_b_done, 0);
       hipLaunchKernelGGL(k_ldlt_panel<PGF_NB>, dim3(std::max(1, (below + 63) / 64)), dim3(256), 0,
                          sA, f.K, f.ldk, Wb, (int64_t)OB, c0 - ob0, N, nrows, c0, f.dvec, f.dinv,
                          f.flags, skip);
       const int c1 = c0 + PGF_NB;
+      if (la_dbg == 2 && b_pending) (void)hipStreamWaitEvent(sA, ev_b_done, 0);
       if (c1 < obEnd)  // inner update: the rest of this outer block's columns, K = 64
         launch_update(f, sA, Wb + (c0 - ob0), OB, N, nrows, c1, c1, obEnd, c0, PGF_NB, p);
     }

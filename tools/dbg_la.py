@@ -2,7 +2,7 @@ import numpy as np, sys
 sys.path.insert(0, ".")
 import pygradflow_amd as pgf
 rng = np.random.default_rng(0)
-for n1, n2 in [(1024, 256), (2048, 512), (3072, 768), (4096, 1024)]:
+for n1, n2 in [(4096, 1024)]:
     G1 = rng.standard_normal((n1, n1)) / np.sqrt(n1)
     A = G1 @ G1.T + np.eye(n1)
     B = rng.standard_normal((n2, n1)) / np.sqrt(n1)
