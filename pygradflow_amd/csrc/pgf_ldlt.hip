@@ -619,7 +619,15 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
     if (obEnd < N) {
       const int KB = obEnd - ob0;  // == OB here (only the last outer block may be short)
       const int nextEnd = std::min(obEnd + OB, N);
-      if (b_pending) (void)hipStreamWaitEvent(sA, ev_b_done, 0);  // RMW order on next block
+      if (b_pending) {
+        if (la_dbg == 6) (void)hipStreamSynchronize(sB);
+        if (la_dbg == 7) {
+          hipEvent_t ex = next_event();
+          (void)hipEventRecord(ex, sB);
+          (void)hipStreamWaitEvent(sA, ex, 0);
+        }
+        (void)hipStreamWaitEvent(sA, ev_b_done, 0);  // RMW order on next block
+      }
       launch_update(f, sA, Wb, OB, N, nrows, obEnd, obEnd, nextEnd, ob0, KB, p);
       if (nextEnd < N) {
         hipEvent_t ev_a = next_event();
