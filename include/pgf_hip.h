@@ -158,6 +158,8 @@ int pgf_ls_create_dense(int N, const double *A, int64_t lda, int symmetric, int 
                         pgf_ls_handle *out);
 int pgf_ls_solve(pgf_ls_handle ls, const double *rhs, int trans, double *sol);
 int pgf_ls_num_neg(pgf_ls_handle ls, int *out);
+/* debug / parity: copy the factor (unit-lower L below the diagonal, D on it) to host */
+int pgf_ls_get_factor(pgf_ls_handle ls, double *LD_out, int64_t ld);
 int pgf_ls_destroy(pgf_ls_handle ls);
 
 #ifdef __cplusplus

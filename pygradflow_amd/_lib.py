@@ -63,6 +63,7 @@ SIGNATURES = {
     "pgf_ls_create_dense": (C.c_int, [C.c_int, _dp, C.c_int64, C.c_int, C.c_int, C.POINTER(_h)]),
     "pgf_ls_solve": (C.c_int, [_h, _dp, C.c_int, _dp]),
     "pgf_ls_num_neg": (C.c_int, [_h, _ip]),
+    "pgf_ls_get_factor": (C.c_int, [_h, _dp, C.c_int64]),
     "pgf_ls_destroy": (C.c_int, [_h]),
 }
 

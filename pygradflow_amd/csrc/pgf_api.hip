@@ -754,6 +754,18 @@ int pgf_ls_solve(pgf_ls_handle ls, const double *rhs, int trans, double *sol) {
   return e == hipSuccess ? PGF_OK : PGF_HIP_ERROR + (int)e;
 }
 
+int pgf_ls_get_factor(pgf_ls_handle ls, double *LD_out, int64_t ld) {
+  if (!ls || (ls->N && (!LD_out || ld < ls->N))) return PGF_INVALID;
+  if (ls->N == 0) return PGF_OK;
+  (void)hipSetDevice(ls->device);
+  hipError_t e = hipMemcpy2DAsync(LD_out, (size_t)ld * sizeof(double), ls->fac.K,
+                                  (size_t)ls->fac.ldk * sizeof(double),
+                                  (size_t)ls->N * sizeof(double), ls->N, hipMemcpyDeviceToHost,
+                                  ls->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ls->stream);
+  return e == hipSuccess ? PGF_OK : PGF_HIP_ERROR + (int)e;
+}
+
 int pgf_ls_num_neg(pgf_ls_handle ls, int *out) {
   if (!ls || !out) return PGF_INVALID;
   *out = ls->fac.n_neg;

@@ -54,6 +54,14 @@ class HipLinearSolver:
         _lib.check(self._lib.pgf_ls_num_neg(self._h, C.byref(out)), None, "pgf_ls_num_neg")
         return out.value
 
+    def factor_matrix(self):
+        """Unit-lower L (below the diagonal) and D (on it), as factored on the device."""
+        n = self.shape[0]
+        out = np.zeros((n, n))
+        if n:
+            _lib.check(self._lib.pgf_ls_get_factor(self._h, _lib.dptr(out), n), None, "pgf_ls_get_factor")
+        return np.tril(out)
+
     def rcond(self):
         return None
 
