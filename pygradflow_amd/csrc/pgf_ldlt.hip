@@ -568,7 +568,13 @@ static void launch_update(DenseLdlt &f, hipStream_t s, const double *Wp, int64_t
 hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
   f.N = N;
   f.factored = false;
-  hipStream_t sA = f.stream, sB = getenv("PGF_NOLOOKAHEAD") ? f.stream : f.stream2;
+  // Look-ahead over a second stream is OFF by default: with two queues resident at once,
+  // kernels on stream A were observed to read stale lines from one XCD's L2 (bad tiles
+  // periodic in 8 workgroups = one XCD; serial execution is always exact).  The event
+  // dependencies below are complete, so this is a cache-visibility effect of concurrent
+  // queues on the non-coherent per-XCD L2s, not a missing edge.  PGF_LOOKAHEAD=1 re-enables
+  // it for investigation.
+  hipStream_t sA = f.stream, sB = getenv("PGF_LOOKAHEAD") ? f.stream2 : f.stream;
   hipError_t e = hipMemsetAsync(f.flags, 0, 4 * sizeof(int), sA);
   if (e != hipSuccess) return e;
   PgfProfile *p = (f.prof && f.prof->enabled) ? f.prof : nullptr;
