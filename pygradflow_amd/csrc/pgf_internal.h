@@ -38,7 +38,7 @@ struct DenseLdlt {
   hipStream_t stream2 = nullptr;  // look-ahead stream (trailing update)
   hipEvent_t ev_panel = nullptr, ev_update = nullptr;
   std::vector<hipEvent_t> ev_ring;  // one event per cross-stream edge of a factorisation
-  int OB = 128;             // outer block width (K-depth of the bulk trailing update)
+  int OB = 256;             // outer block width (K-depth of the bulk trailing update)
   size_t wstride = 0;       // doubles per W buffer (two buffers)
   int N = 0;
   bool factored = false;

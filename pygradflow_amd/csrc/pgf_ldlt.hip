@@ -15,6 +15,7 @@
 #include "pgf_internal.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -58,22 +59,25 @@ __device__ __forceinline__ double fast_recip(double d) {
 #define PNL_LD 66   // LDS row stride of M: conflict-free MFMA fragment reads, 16 B rows
 #define PNL_WLD 18
 
+#define PNL_SMEM (128 * PNL_LD * 8 + 128 * PNL_WLD * 8 + 2 * 64 * 8 + 16)
+
 template <int NB>
-__global__ __launch_bounds__(256) void k_ldlt_panel(double *__restrict__ K, int64_t ldk,
-                                                    double *__restrict__ W, int64_t ldw, int wofs,
-                                                    int N, int nrows, int c0,
-                                                    double *__restrict__ dvec,
-                                                    double *__restrict__ dinv,
-                                                    int *__restrict__ flags, int skip) {
+__device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
+                                           double *__restrict__ K, int64_t ldk,
+                                           double *__restrict__ W, int64_t ldw, int wofs, int N,
+                                           int nrows, int c0, double *__restrict__ dvec,
+                                           double *__restrict__ dinv, int *__restrict__ flags,
+                                           int skip) {
   static_assert(NB == 64, "panel kernel is written for 64-column panels");
-  __shared__ __attribute__((aligned(16))) double M[128][PNL_LD];
-  __shared__ __attribute__((aligned(16))) double Wt[128][PNL_WLD];
-  __shared__ double dD[NB], dI[NB];
-  __shared__ int s_bad;
+  double(*M)[PNL_LD] = reinterpret_cast<double(*)[PNL_LD]>(smem);
+  double(*Wt)[PNL_WLD] = reinterpret_cast<double(*)[PNL_WLD]>(smem + 128 * PNL_LD * 8);
+  double *dD = reinterpret_cast<double *>(smem + 128 * PNL_LD * 8 + 128 * PNL_WLD * 8);
+  double *dI = dD + 64;
+  int &s_bad = *reinterpret_cast<int *>(dI + 64);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int nb = min(NB, N - c0);
-  const int rbase = c0 + nb + blockIdx.x * 64;  // first own row (global)
+  const int rbase = c0 + nb + wg * 64;  // first own row (global)
   if (tid == 0) s_bad = 0;
 
   // ---- load: diag block (identity outside the valid lower triangle) + own rows.
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(256) void k_ldlt_panel(double *__restrict__ K, int6
       else if (c2 < nb) dst[0] = v.x;
     }
   }
-  if (blockIdx.x == 0) {
+  if (wg == 0) {
     for (int p = tid; p < 64 * 64; p += 256) {
       const int row = p >> 6, c = p & 63;
       if (row < nb && c <= row) K[(int64_t)(c0 + row) * ldk + c0 + c] = M[row][c];
@@ -267,18 +271,15 @@ __global__ __launch_bounds__(256) void k_ldlt_panel(double *__restrict__ K, int6
 // outer block, where 128-wide tiles would leave most CUs idle); 4 wavefronts as 2 x 2,
 // each (BT/2) x (BT/2) = TT x TT MFMA tiles.
 template <int BT>
-__global__ __launch_bounds__(256, 2) void k_ldlt_update(double *__restrict__ K, int64_t ldk,
-                                                        const double *__restrict__ W,
-                                                        int64_t ldw, int N, int nrows, int row0,
-                                                        int col0, int colEnd, int kc0, int KB) {
+__device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, const int j0,
+                                            double *__restrict__ K, int64_t ldk,
+                                            const double *__restrict__ W, int64_t ldw, int N,
+                                            int nrows, int colEnd, int kc0, int KB) {
   constexpr int TT = BT / 32;          // MFMA tiles per wavefront and dimension
   constexpr int WT = BT / 2;           // rows / columns per wavefront
   constexpr int PIECES = BT * 8 / 256; // 16-byte staging pieces per lane and operand
-  const int i0 = row0 + blockIdx.y * BT;
-  const int j0 = col0 + blockIdx.x * BT;
-  if (j0 > i0 + BT - 1) return;  // tile entirely above the diagonal
-  __shared__ __attribute__((aligned(16))) double As[BT][UPD_LDS];
-  __shared__ __attribute__((aligned(16))) double Bs[BT][UPD_LDS];
+  double(*As)[UPD_LDS] = reinterpret_cast<double(*)[UPD_LDS]>(smem);
+  double(*Bs)[UPD_LDS] = reinterpret_cast<double(*)[UPD_LDS]>(smem + BT * UPD_LDS * 8);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -365,6 +366,56 @@ __global__ __launch_bounds__(256, 2) void k_ldlt_update(double *__restrict__ K, 
         if (i < nrows && j < colEnd && j <= i) K[(int64_t)i * ldk + j] = acc[mi][nj][r];
       }
     }
+  }
+}
+
+template <int BT>
+__global__ __launch_bounds__(256, 2) void k_ldlt_update(double *__restrict__ K, int64_t ldk,
+                                                        const double *__restrict__ W,
+                                                        int64_t ldw, int N, int nrows, int row0,
+                                                        int col0, int colEnd, int kc0, int KB) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BT * UPD_LDS * 8];
+  const int i0 = row0 + blockIdx.y * BT;
+  const int j0 = col0 + blockIdx.x * BT;
+  if (j0 > i0 + BT - 1) return;  // tile entirely above the diagonal
+  update_tile<BT>(smem, i0, j0, K, ldk, W, ldw, N, nrows, colEnd, kc0, KB);
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void k_ldlt_panel(double *__restrict__ K, int64_t ldk,
+                                                    double *__restrict__ W, int64_t ldw, int wofs,
+                                                    int N, int nrows, int c0,
+                                                    double *__restrict__ dvec,
+                                                    double *__restrict__ dinv,
+                                                    int *__restrict__ flags, int skip) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[PNL_SMEM];
+  panel_body<NB>(smem, blockIdx.x, K, ldk, W, ldw, wofs, N, nrows, c0, dvec, dinv, flags, skip);
+}
+
+// Panel launch that also carries "filler" workgroups: 128 x 128 tiles of the PREVIOUS outer
+// block's bulk trailing update (columns beyond the current outer block), which touch
+// nothing the panel reads or writes.  This is the look-ahead of the blocked
+// factorisation, obtained inside one queue: the CUs the panel cannot use (it has ~N/64
+// workgroups and is latency-bound) run MFMA tiles instead of idling.  No data is handed
+// between workgroups of the launch, so ordinary kernel-boundary visibility suffices.
+// Tiles are numbered over the lower triangle of the region: t -> (ti, tj), tj <= ti.
+template <int NB>
+__global__ __launch_bounds__(256, 2) void k_ldlt_panel_fused(
+    double *__restrict__ K, int64_t ldk, double *__restrict__ W, int64_t ldw, int wofs, int N,
+    int nrows, int c0, double *__restrict__ dvec, double *__restrict__ dinv,
+    int *__restrict__ flags, int skip, int n_panel_wg, const double *__restrict__ Wprev,
+    int64_t ldwp, int ureg0, int ukc0, int uKB, int tile_start) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[PNL_SMEM];
+  if ((int)blockIdx.x < n_panel_wg) {
+    panel_body<NB>(smem, blockIdx.x, K, ldk, W, ldw, wofs, N, nrows, c0, dvec, dinv, flags, skip);
+  } else {
+    const int t = tile_start + (int)blockIdx.x - n_panel_wg;
+    int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    update_tile<UPD_BM>(smem, ureg0 + ti * UPD_BM, ureg0 + tj * UPD_BM, K, ldk, Wprev, ldwp, N,
+                        nrows, N, ukc0, uKB);
   }
 }
 
@@ -476,7 +527,7 @@ hipError_t ldlt_alloc(DenseLdlt &f, int Nmax, hipStream_t stream) {
   hipError_t e;
   const size_t rows = (size_t)Nmax + 1 + PGF_NB;
   if ((e = hipMalloc(&f.K, rows * f.ldk * sizeof(double))) != hipSuccess) return e;
-  f.OB = 128;
+  f.OB = 256;
   if (const char *ob = getenv("PGF_OB")) {
     const int v = atoi(ob);
     if (v == 64 || v == 128 || v == 192 || v == 256) f.OB = v;
@@ -559,22 +610,18 @@ static void launch_update(DenseLdlt &f, hipStream_t s, const double *Wp, int64_t
   }
 }
 
-// Two-level right-looking factorisation with a depth-1 look-ahead over two streams.
-//   outer block (f.OB columns):  inner 64-column panels  [stream A]
-//                                inner updates restricted to the outer block, K = 64 [A]
-//   bulk update with K = OB:     next outer block's columns [A]  ||  the rest [B]
+// Two-level right-looking factorisation.
+//   outer block (f.OB columns):  inner 64-column panels
+//                                inner updates restricted to the outer block, K = 64
+//   bulk update with K = OB:     next outer block's columns right away (the next panels
+//                                need them); the rest as FILLER tiles carried by the next
+//                                outer block's panel launches (look-ahead inside one queue)
 // W (= L D of the current outer block, OB columns wide) is double buffered because the
-// bulk update on stream B still reads it while stream A factors the next outer block.
+// filler tiles of block i still read it while the panels of block i + 1 write theirs.
 hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
   f.N = N;
   f.factored = false;
-  // Look-ahead over a second stream is OFF by default: with two queues resident at once,
-  // kernels on stream A were observed to read stale lines from one XCD's L2 (bad tiles
-  // periodic in 8 workgroups = one XCD; serial execution is always exact).  The event
-  // dependencies below are complete, so this is a cache-visibility effect of concurrent
-  // queues on the non-coherent per-XCD L2s, not a missing edge.  PGF_LOOKAHEAD=1 re-enables
-  // it for investigation.
-  hipStream_t sA = f.stream, sB = getenv("PGF_LOOKAHEAD") ? f.stream2 : f.stream;
+  hipStream_t sA = f.stream;
   hipError_t e = hipMemsetAsync(f.flags, 0, 4 * sizeof(int), sA);
   if (e != hipSuccess) return e;
   PgfProfile *p = (f.prof && f.prof->enabled) ? f.prof : nullptr;
@@ -590,63 +637,84 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
   }
   const int OB = f.OB;
   const int skip = getenv("PGF_SKIP") ? atoi(getenv("PGF_SKIP")) : 0;
-  const int la_dbg = getenv("PGF_LA_DEBUG") ? atoi(getenv("PGF_LA_DEBUG")) : 0;
-  bool b_pending = false;
+  const bool fuse = getenv("PGF_NOFUSE") == nullptr;
+  // pending bulk update (previous outer block): region [reg0, nrows) x [reg0, N)
+  struct {
+    bool active = false;
+    const double *Wp = nullptr;
+    int reg0 = 0, kc0 = 0, KB = 0, total = 0, done = 0;
+  } pend;
   int buf = 0;
-  int evi = 0;
-  auto next_event = [&]() -> hipEvent_t {
-    if ((size_t)evi >= f.ev_ring.size()) {
-      hipEvent_t ev;
-      (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-      f.ev_ring.push_back(ev);
-    }
-    return f.ev_ring[evi++];
-  };
-  hipEvent_t ev_b_done = nullptr;
-  // stream B must not start before everything already queued on A (assembly, rhs row)
-  (void)hipEventRecord(f.ev_panel, sA);
-  (void)hipStreamWaitEvent(sB, f.ev_panel, 0);
   for (int ob0 = 0; ob0 < N; ob0 += OB, buf ^= 1) {
     const int obEnd = std::min(ob0 + OB, N);
     double *Wb = f.W + (size_t)buf * f.wstride;
-    for (int c0 = ob0; c0 < obEnd; c0 += PGF_NB) {
+    const int npanels = (obEnd - ob0 + PGF_NB - 1) / PGF_NB;
+    int k = 0;
+    for (int c0 = ob0; c0 < obEnd; c0 += PGF_NB, ++k) {
       const int below = nrows - std::min(c0 + PGF_NB, N);
-      if (la_dbg == 1 && b_pending) (void)hipStreamWaitEvent(sA, ev_b_done, 0);
-      if (la_dbg == 4 && b_pending && c0 == ob0) (void)hipStreamWaitEvent(sA, ev_b_done, 0);
-      if (la_dbg == 5 && b_pending && c0 != ob0) (void)hipStreamWaitEvent(sA, ev_b_done, 0);
-      hipLaunchKernelGGL(k_ldlt_panel<PGF_NB>, dim3(std::max(1, (below + 63) / 64)), dim3(256), 0,
-                         sA, f.K, f.ldk, Wb, (int64_t)OB, c0 - ob0, N, nrows, c0, f.dvec, f.dinv,
-                         f.flags, skip);
+      const int npw = std::max(1, (below + 63) / 64);
+      const int remaining = pend.active ? pend.total - pend.done : 0;
+      if (remaining > 0) {
+        const int share = (remaining + (npanels - k) - 1) / (npanels - k);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (p) {
+          e0 = prof_event(p);
+          e1 = prof_event(p);
+          (void)hipEventRecord(e0, sA);
+        }
+        hipLaunchKernelGGL(k_ldlt_panel_fused<PGF_NB>, dim3(npw + share), dim3(256), 0, sA, f.K,
+                           f.ldk, Wb, (int64_t)OB, c0 - ob0, N, nrows, c0, f.dvec, f.dinv, f.flags,
+                           skip, npw, pend.Wp, (int64_t)OB, pend.reg0, pend.kc0, pend.KB,
+                           pend.done);
+        if (p) {
+          (void)hipEventRecord(e1, sA);
+          p->update_spans.emplace_back(e0, e1);
+          // algorithmic flops of the filler tiles of this launch (lower triangle only)
+          double cnt = 0.0;
+          for (int t = pend.done; t < pend.done + share; ++t) {
+            int ti = (int)((std::sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+            while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+            while (ti * (ti + 1) / 2 > t) --ti;
+            const int tj = t - ti * (ti + 1) / 2;
+            const int r0 = pend.reg0 + ti * UPD_BM, c0t = pend.reg0 + tj * UPD_BM;
+            const int r1 = std::min(r0 + UPD_BM, nrows), c1t = std::min(c0t + UPD_BM, N);
+            for (int i = r0; i < r1; ++i) {
+              const int top = std::min(c1t, i + 1);
+              if (top > c0t) cnt += top - c0t;
+            }
+          }
+          p->update_flops.push_back(2.0 * cnt * pend.KB);
+        }
+        pend.done += share;
+      } else {
+        hipLaunchKernelGGL(k_ldlt_panel<PGF_NB>, dim3(npw), dim3(256), 0, sA, f.K, f.ldk, Wb,
+                           (int64_t)OB, c0 - ob0, N, nrows, c0, f.dvec, f.dinv, f.flags, skip);
+      }
       const int c1 = c0 + PGF_NB;
-      if (la_dbg == 2 && b_pending) (void)hipStreamWaitEvent(sA, ev_b_done, 0);
       if (c1 < obEnd)  // inner update: the rest of this outer block's columns, K = 64
         launch_update(f, sA, Wb + (c0 - ob0), OB, N, nrows, c1, c1, obEnd, c0, PGF_NB, p);
     }
+    pend.active = false;
     if (obEnd < N) {
       const int KB = obEnd - ob0;  // == OB here (only the last outer block may be short)
       const int nextEnd = std::min(obEnd + OB, N);
-      if (b_pending) {
-        if (la_dbg == 6) (void)hipStreamSynchronize(sB);
-        if (la_dbg == 7) {
-          hipEvent_t ex = next_event();
-          (void)hipEventRecord(ex, sB);
-          (void)hipStreamWaitEvent(sA, ex, 0);
-        }
-        (void)hipStreamWaitEvent(sA, ev_b_done, 0);  // RMW order on next block
-      }
       launch_update(f, sA, Wb, OB, N, nrows, obEnd, obEnd, nextEnd, ob0, KB, p);
       if (nextEnd < N) {
-        hipEvent_t ev_a = next_event();
-        (void)hipEventRecord(ev_a, sA);
-        (void)hipStreamWaitEvent(sB, ev_a, 0);
-        launch_update(f, sB, Wb, OB, N, nrows, nextEnd, nextEnd, N, ob0, KB, p);
-        ev_b_done = next_event();
-        (void)hipEventRecord(ev_b_done, sB);
-        b_pending = true;
+        if (fuse) {
+          const int TR = (nrows - nextEnd + UPD_BM - 1) / UPD_BM;
+          pend.active = true;
+          pend.Wp = Wb;
+          pend.reg0 = nextEnd;
+          pend.kc0 = ob0;
+          pend.KB = KB;
+          pend.total = TR * (TR + 1) / 2;
+          pend.done = 0;
+        } else {
+          launch_update(f, sA, Wb, OB, N, nrows, nextEnd, nextEnd, N, ob0, KB, p);
+        }
       }
     }
   }
-  if (b_pending) (void)hipStreamWaitEvent(sA, ev_b_done, 0);
   if (p) (void)hipEventRecord(p->factor_span.second, sA);
   e = hipMemcpyAsync(f.h_flags, f.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, sA);
   if (e != hipSuccess) return e;
