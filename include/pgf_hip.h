@@ -162,6 +162,13 @@ int pgf_ls_num_neg(pgf_ls_handle ls, int *out);
 int pgf_ls_get_factor(pgf_ls_handle ls, double *LD_out, int64_t ld);
 int pgf_ls_destroy(pgf_ls_handle ls);
 
+/* ---- kernel micro-benchmark hook (tools/, bench diagnostics) ------------------ */
+/* Times `reps` launches of the factorisation's trailing-update kernel on a synthetic
+ * N x N lower-triangular region with K-depth KB (variant selects the tile kernel);
+ * returns the mean launch time in ms and the algorithmic flops of one launch. */
+int pgf_bench_update(int N, int KB, int variant, int reps, int device, double *ms_out,
+                     double *flops_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,7 @@ SIGNATURES = {
     "pgf_ls_num_neg": (C.c_int, [_h, _ip]),
     "pgf_ls_get_factor": (C.c_int, [_h, _dp, C.c_int64]),
     "pgf_ls_destroy": (C.c_int, [_h]),
+    "pgf_bench_update": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]),
 }
 
 _lib = None

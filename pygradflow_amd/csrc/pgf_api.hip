@@ -784,4 +784,12 @@ int pgf_ls_destroy(pgf_ls_handle ls) {
   return PGF_OK;
 }
 
+int pgf_bench_update(int N, int KB, int variant, int reps, int device, double *ms_out,
+                     double *flops_out) {
+  if (N <= 0 || KB <= 0 || KB % 16 || reps <= 0 || !ms_out || !flops_out) return PGF_INVALID;
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = ldlt_bench_update(N, KB, variant, reps, ms_out, flops_out);
+  return e == hipSuccess ? PGF_OK : PGF_HIP_ERROR + (int)e;
+}
+
 }  // extern "C"

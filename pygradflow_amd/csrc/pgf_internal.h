@@ -59,3 +59,7 @@ hipError_t ldlt_backsolve_async(DenseLdlt &f, const double *w, double *sol);
 
 // ---- elementwise / assembly launches (pgf_kernels.hip) --------------------
 struct StepDev;  // opaque here
+
+// micro-benchmark of the trailing update (pgf_ldlt.hip)
+hipError_t ldlt_bench_update(int N, int KB, int variant, int reps, double *ms_out,
+                             double *flops_out);

@@ -761,3 +761,57 @@ hipError_t ldlt_solve_async(DenseLdlt &f, const double *rhs, double *sol) {
   // backward: L^T s = y
   return ldlt_backsolve_async(f, sol, sol);
 }
+
+// ------------------------------------------------------------------ micro-benchmark
+__global__ void k_fill_pattern(double *p, size_t n, double scale) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = scale * (double)((i * 2654435761ull) % 1000003ull) / 1000003.0 - 0.5 * scale;
+}
+
+hipError_t ldlt_bench_update(int N, int KB, int variant, int reps, double *ms_out,
+                             double *flops_out) {
+  DenseLdlt f;
+  hipStream_t s;
+  hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (e != hipSuccess) return e;
+  f.OB = KB;
+  f.ldk = pick_ldk(N + KB);
+  f.stream = s;
+  const size_t rows = (size_t)N + KB + 1;
+  if ((e = hipMalloc(&f.K, rows * f.ldk * sizeof(double))) != hipSuccess) return e;
+  if ((e = hipMalloc(&f.W, rows * KB * sizeof(double))) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_fill_pattern, dim3((rows * f.ldk + 255) / 256), dim3(256), 0, s, f.K,
+                     rows * f.ldk, 1.0);
+  hipLaunchKernelGGL(k_fill_pattern, dim3((rows * KB + 255) / 256), dim3(256), 0, s, f.W,
+                     rows * (size_t)KB, 1e-3);
+  // region: rows/cols [KB, KB + N), L panel in columns [0, KB)
+  const int Nt = N + KB;
+  auto launch = [&]() {
+    const int bt = (variant == 64) ? 64 : UPD_BM;
+    const int tr = (N + bt - 1) / bt;
+    if (variant == 64)
+      hipLaunchKernelGGL(k_ldlt_update<64>, dim3(tr, tr), dim3(256), 0, s, f.K, f.ldk, f.W,
+                         (int64_t)KB, Nt, Nt, KB, KB, Nt, 0, KB);
+    else
+      hipLaunchKernelGGL(k_ldlt_update<128>, dim3(tr, tr), dim3(256), 0, s, f.K, f.ldk, f.W,
+                         (int64_t)KB, Nt, Nt, KB, KB, Nt, 0, KB);
+  };
+  launch();
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, s);
+  for (int r = 0; r < reps; ++r) launch();
+  (void)hipEventRecord(e1, s);
+  e = hipStreamSynchronize(s);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  *ms_out = ms / reps;
+  *flops_out = (double)N * ((double)N + 1.0) * KB;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(f.K);
+  (void)hipFree(f.W);
+  (void)hipStreamDestroy(s);
+  return e;
+}
