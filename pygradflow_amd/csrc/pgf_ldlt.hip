@@ -264,22 +264,21 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
 // prefetched into registers; LDS rows padded to 18 doubles (conflict-free ds_read_b64
 // for the fragment pattern, 16-byte aligned ds_write_b128).
 #define UPD_BM 128
-#define UPD_BK 16
-#define UPD_LDS 18
 
-// BT = tile edge (128: bulk regions, 64: narrow regions such as the inner updates of an
-// outer block, where 128-wide tiles would leave most CUs idle); 4 wavefronts as 2 x 2,
-// each (BT/2) x (BT/2) = TT x TT MFMA tiles.
-template <int BT>
+// BM x BN = tile (rows x columns); BK = K-chunk staged per barrier pair; 4 wavefronts as
+// 2 x 2, each (BM/2) x (BN/2) = TM x TN MFMA tiles.  LDS rows are padded to BK + 2 doubles.
+template <int BM, int BN, int BK>
 __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, const int j0,
                                             double *__restrict__ K, int64_t ldk,
                                             const double *__restrict__ W, int64_t ldw, int N,
                                             int nrows, int colEnd, int kc0, int KB) {
-  constexpr int TT = BT / 32;          // MFMA tiles per wavefront and dimension
-  constexpr int WT = BT / 2;           // rows / columns per wavefront
-  constexpr int PIECES = BT * 8 / 256; // 16-byte staging pieces per lane and operand
-  double(*As)[UPD_LDS] = reinterpret_cast<double(*)[UPD_LDS]>(smem);
-  double(*Bs)[UPD_LDS] = reinterpret_cast<double(*)[UPD_LDS]>(smem + BT * UPD_LDS * 8);
+  constexpr int TM = BM / 32, TN = BN / 32;  // MFMA tiles per wavefront
+  constexpr int WM = BM / 2, WN = BN / 2;    // rows / columns per wavefront
+  constexpr int LD = BK + 2;
+  constexpr int PPR = BK / 2;                // 16-byte pieces per row
+  constexpr int PA = BM * PPR / 256, PB = BN * PPR / 256;
+  double(*As)[LD] = reinterpret_cast<double(*)[LD]>(smem);
+  double(*Bs)[LD] = reinterpret_cast<double(*)[LD]>(smem + BM * LD * 8);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -288,15 +287,15 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, c
 
   // accumulators <- C tile (entries above the diagonal / outside the region are never
   // stored back; whatever they hold stays confined to its own accumulator element)
-  double4_t acc[TT][TT];
+  double4_t acc[TM][TN];
 #pragma unroll
-  for (int mi = 0; mi < TT; ++mi) {
+  for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
-    for (int nj = 0; nj < TT; ++nj) {
-      const int j = j0 + wc * WT + nj * 16 + l15;
+    for (int nj = 0; nj < TN; ++nj) {
+      const int j = j0 + wc * WN + nj * 16 + l15;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = i0 + wr * WT + mi * 16 + l4 + 4 * r;
+        const int i = i0 + wr * WM + mi * 16 + l4 + 4 * r;
         double v = 0.0;
         if (i < nrows && j < colEnd && j <= i) v = K[(int64_t)i * ldk + j];
         acc[mi][nj][r] = v;
@@ -304,81 +303,90 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, c
     }
   }
 
-  // staging map: piece p = q*256 + tid -> row p>>3, two doubles at column (p&7)*2
-  double2_t pa[PIECES], pb[PIECES];
+  // staging map: piece p = q*256 + tid -> row p / PPR, two doubles at column (p % PPR)*2
+  double2_t pa[PA], pb[PB];
   auto fetch = [&](int kk) {
 #pragma unroll
-    for (int q = 0; q < PIECES; ++q) {
+    for (int q = 0; q < PA; ++q) {
       const int p = q * 256 + tid;
-      const int row = p >> 3, kofs = (p & 7) * 2;
-      const int gi = i0 + row, gj = j0 + row;
-      double2_t va = (double2_t){0.0, 0.0}, vb = (double2_t){0.0, 0.0};
+      const int row = p / PPR, kofs = (p % PPR) * 2;
+      const int gi = i0 + row;
+      double2_t va = (double2_t){0.0, 0.0};
       if (gi < nrows) va = *reinterpret_cast<const double2_t *>(W + (int64_t)gi * ldw + kk + kofs);
+      pa[q] = va;
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      const int p = q * 256 + tid;
+      const int row = p / PPR, kofs = (p % PPR) * 2;
+      const int gj = j0 + row;
+      double2_t vb = (double2_t){0.0, 0.0};
       if (gj < colEnd)
         vb = *reinterpret_cast<const double2_t *>(K + (int64_t)gj * ldk + kc0 + kk + kofs);
-      pa[q] = va;
       pb[q] = vb;
     }
   };
   auto stage = [&]() {
+    // negate here, not at the fetch: touching the loaded value there would make the
+    // wavefront wait for the prefetch before it starts the current chunk's MFMAs
 #pragma unroll
-    for (int q = 0; q < PIECES; ++q) {
+    for (int q = 0; q < PA; ++q) {
       const int p = q * 256 + tid;
-      const int row = p >> 3, kofs = (p & 7) * 2;
-      // negate here, not at the fetch: touching the loaded value there would make the
-      // wavefront wait for the prefetch before it starts the current chunk's MFMAs
-      *reinterpret_cast<double2_t *>(&As[row][kofs]) = -pa[q];
-      *reinterpret_cast<double2_t *>(&Bs[row][kofs]) = pb[q];
+      *reinterpret_cast<double2_t *>(&As[p / PPR][(p % PPR) * 2]) = -pa[q];
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      const int p = q * 256 + tid;
+      *reinterpret_cast<double2_t *>(&Bs[p / PPR][(p % PPR) * 2]) = pb[q];
     }
   };
 
   fetch(0);
-  for (int kk = 0; kk < KB; kk += UPD_BK) {
+  for (int kk = 0; kk < KB; kk += BK) {
     __syncthreads();  // previous chunk's fragment reads are done
     stage();
     __syncthreads();
-    if (kk + UPD_BK < KB) fetch(kk + UPD_BK);
+    if (kk + BK < KB) fetch(kk + BK);
 #pragma unroll
-    for (int ks = 0; ks < UPD_BK; ks += 4) {
-      double a[TT], b[TT];
+    for (int ks = 0; ks < BK; ks += 4) {
+      double a[TM], b[TN];
 #pragma unroll
-      for (int t = 0; t < TT; ++t) {
-        a[t] = As[wr * WT + t * 16 + l15][ks + l4];
-        b[t] = Bs[wc * WT + t * 16 + l15][ks + l4];
-      }
+      for (int t = 0; t < TM; ++t) a[t] = As[wr * WM + t * 16 + l15][ks + l4];
 #pragma unroll
-      for (int mi = 0; mi < TT; ++mi)
+      for (int t = 0; t < TN; ++t) b[t] = Bs[wc * WN + t * 16 + l15][ks + l4];
 #pragma unroll
-        for (int nj = 0; nj < TT; ++nj)
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < TN; ++nj)
           acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
     }
   }
 
   // epilogue: store-only, lower triangle of the region
 #pragma unroll
-  for (int mi = 0; mi < TT; ++mi) {
+  for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
-    for (int nj = 0; nj < TT; ++nj) {
-      const int j = j0 + wc * WT + nj * 16 + l15;
+    for (int nj = 0; nj < TN; ++nj) {
+      const int j = j0 + wc * WN + nj * 16 + l15;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = i0 + wr * WT + mi * 16 + l4 + 4 * r;
+        const int i = i0 + wr * WM + mi * 16 + l4 + 4 * r;
         if (i < nrows && j < colEnd && j <= i) K[(int64_t)i * ldk + j] = acc[mi][nj][r];
       }
     }
   }
 }
 
-template <int BT>
-__global__ __launch_bounds__(256, 2) void k_ldlt_update(double *__restrict__ K, int64_t ldk,
-                                                        const double *__restrict__ W,
-                                                        int64_t ldw, int N, int nrows, int row0,
-                                                        int col0, int colEnd, int kc0, int KB) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BT * UPD_LDS * 8];
-  const int i0 = row0 + blockIdx.y * BT;
-  const int j0 = col0 + blockIdx.x * BT;
-  if (j0 > i0 + BT - 1) return;  // tile entirely above the diagonal
-  update_tile<BT>(smem, i0, j0, K, ldk, W, ldw, N, nrows, colEnd, kc0, KB);
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__(256) void k_ldlt_update(double *__restrict__ K, int64_t ldk,
+                                                     const double *__restrict__ W, int64_t ldw,
+                                                     int N, int nrows, int row0, int col0,
+                                                     int colEnd, int kc0, int KB) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * (BK + 2) * 8];
+  const int i0 = row0 + blockIdx.y * BM;
+  const int j0 = col0 + blockIdx.x * BN;
+  if (j0 > i0 + BM - 1) return;  // tile entirely above the diagonal
+  update_tile<BM, BN, BK>(smem, i0, j0, K, ldk, W, ldw, N, nrows, colEnd, kc0, KB);
 }
 
 template <int NB>
@@ -414,8 +422,8 @@ __global__ __launch_bounds__(256, 2) void k_ldlt_panel_fused(
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     while (ti * (ti + 1) / 2 > t) --ti;
     const int tj = t - ti * (ti + 1) / 2;
-    update_tile<UPD_BM>(smem, ureg0 + ti * UPD_BM, ureg0 + tj * UPD_BM, K, ldk, Wprev, ldwp, N,
-                        nrows, N, ukc0, uKB);
+    update_tile<UPD_BM, UPD_BM, 16>(smem, ureg0 + ti * UPD_BM, ureg0 + tj * UPD_BM, K, ldk, Wprev,
+                                    ldwp, N, nrows, N, ukc0, uKB);
   }
 }
 
@@ -577,10 +585,10 @@ static void launch_update(DenseLdlt &f, hipStream_t s, const double *Wp, int64_t
                           int nrows, int row0, int col0, int colEnd, int kc0, int KB,
                           PgfProfile *p) {
   if (row0 >= nrows || col0 >= colEnd) return;
-  // narrow regions (inner updates, next-block update) get 64 x 64 tiles: a 128-wide tile
-  // grid would occupy only ~40 of the 256 CUs
-  const bool narrow = (colEnd - col0) <= 256;
-  const int bt = narrow ? 64 : UPD_BM;
+  // 64 x 64 tiles (96 VGPRs, 5 wavefronts per SIMD) beat 128 x 128 tiles (249 VGPRs, 2 per
+  // SIMD) at every region size measured (tools/bench_update.py): the kernel lives on
+  // occupancy to hide its LDS / global latencies.
+  const int bt = 64;
   const int tr = (nrows - row0 + bt - 1) / bt;
   const int tc = (colEnd - col0 + bt - 1) / bt;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -589,12 +597,8 @@ static void launch_update(DenseLdlt &f, hipStream_t s, const double *Wp, int64_t
     e1 = prof_event(p);
     (void)hipEventRecord(e0, s);
   }
-  if (narrow)
-    hipLaunchKernelGGL(k_ldlt_update<64>, dim3(tc, tr), dim3(256), 0, s, f.K, f.ldk, Wp, ldw, N,
-                       nrows, row0, col0, colEnd, kc0, KB);
-  else
-    hipLaunchKernelGGL(k_ldlt_update<128>, dim3(tc, tr), dim3(256), 0, s, f.K, f.ldk, Wp, ldw, N,
-                       nrows, row0, col0, colEnd, kc0, KB);
+  hipLaunchKernelGGL((k_ldlt_update<64, 64, 16>), dim3(tc, tr), dim3(256), 0, s, f.K, f.ldk, Wp,
+                     ldw, N, nrows, row0, col0, colEnd, kc0, KB);
   if (p) {
     (void)hipEventRecord(e1, s);
     p->update_spans.emplace_back(e0, e1);
@@ -787,14 +791,20 @@ hipError_t ldlt_bench_update(int N, int KB, int variant, int reps, double *ms_ou
   // region: rows/cols [KB, KB + N), L panel in columns [0, KB)
   const int Nt = N + KB;
   auto launch = [&]() {
-    const int bt = (variant == 64) ? 64 : UPD_BM;
-    const int tr = (N + bt - 1) / bt;
-    if (variant == 64)
-      hipLaunchKernelGGL(k_ldlt_update<64>, dim3(tr, tr), dim3(256), 0, s, f.K, f.ldk, f.W,
-                         (int64_t)KB, Nt, Nt, KB, KB, Nt, 0, KB);
-    else
-      hipLaunchKernelGGL(k_ldlt_update<128>, dim3(tr, tr), dim3(256), 0, s, f.K, f.ldk, f.W,
-                         (int64_t)KB, Nt, Nt, KB, KB, Nt, 0, KB);
+#define PGF_LAUNCH_VARIANT(BM_, BN_, BK_)                                                       \
+  hipLaunchKernelGGL((k_ldlt_update<BM_, BN_, BK_>), dim3((N + BN_ - 1) / BN_, (N + BM_ - 1) / BM_), \
+                     dim3(256), 0, s, f.K, f.ldk, f.W, (int64_t)KB, Nt, Nt, KB, KB, Nt, 0, KB)
+    switch (variant) {
+      case 0: PGF_LAUNCH_VARIANT(64, 64, 16); break;
+      case 1: PGF_LAUNCH_VARIANT(64, 64, 32); break;
+      case 2: PGF_LAUNCH_VARIANT(128, 64, 16); break;
+      case 3: PGF_LAUNCH_VARIANT(64, 128, 16); break;
+      case 4: PGF_LAUNCH_VARIANT(128, 128, 16); break;
+      case 5: PGF_LAUNCH_VARIANT(128, 64, 32); break;
+      case 6: PGF_LAUNCH_VARIANT(128, 128, 32); break;
+      default: PGF_LAUNCH_VARIANT(64, 64, 16); break;
+    }
+#undef PGF_LAUNCH_VARIANT
   };
   launch();
   hipEvent_t e0, e1;
