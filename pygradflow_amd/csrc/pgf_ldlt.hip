@@ -641,7 +641,9 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
   }
   const int OB = f.OB;
   const int skip = getenv("PGF_SKIP") ? atoi(getenv("PGF_SKIP")) : 0;
-  const bool fuse = getenv("PGF_NOFUSE") == nullptr;
+  // filler tiles in the panel launches: correct, but not yet a win (the panel's 87 KB of
+  // LDS leaves one filler workgroup per CU, and the tile kernel needs several per SIMD)
+  const bool fuse = getenv("PGF_FUSE") != nullptr;
   // pending bulk update (previous outer block): region [reg0, nrows) x [reg0, N)
   struct {
     bool active = false;
