@@ -36,9 +36,12 @@ sys.path.insert(0, REPO)
 PEAK_FP64_MFMA_TFLOPS = 78.6
 
 WORKLOADS = {
-    "dense_qp_n4096_m1024": dict(n=4096, m=1024),   # BASELINE configs[1]
-    "dense_qp_n1024_m256": dict(n=1024, m=256),     # element of configs[3]
-    "dense_qp_n512_m128": dict(n=512, m=128),       # quick check
+    "dense_qp_n4096_m1024": dict(n=4096, m=1024, batch=1),   # BASELINE configs[1]
+    "dense_qp_n1024_m256": dict(n=1024, m=256, batch=1),     # element of configs[3]
+    "dense_qp_n512_m128": dict(n=512, m=128, batch=1),       # quick check
+    # BASELINE configs[3]: 256 instances sharded over the ranks (32 per GPU at 8 GPUs);
+    # a "step" is one Newton step of EVERY instance + one all-gather of 256 norms
+    "batch256_n1024_m256": dict(n=1024, m=256, batch=256),
 }
 
 
@@ -61,6 +64,70 @@ def cpu_baseline(problem, max_seconds):
         if el > max_seconds or steps >= 20:
             break
     return steps / el, recs, steps, el
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc
+    passes (profiles/pmc_traffic.json, produced by tools/pmc_summary.py with the gfx950
+    FETCH_SIZE x2 correction of MI355X_MICROARCH.md); None if no such measurement."""
+    path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            rec = json.load(fh)
+        return rec.get(kernel, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def bench_batched(args, wl, rank, local_rank, world, dist, torch):
+    """BASELINE configs[3]: B independent instances, contiguous shards per rank."""
+    from pygradflow_amd import problems
+    from pygradflow_amd.batched import BatchedDeviceNewton
+
+    n, m, B = wl["n"], wl["m"], wl["batch"]
+    bd = BatchedDeviceNewton(lambda i: problems.dense_qp(n, m, seed=i), B, "Full", 1.0, 1.0,
+                             device=local_rank, rank=rank, world=world)
+    dev = torch.device("cuda", local_rank)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    def one_step(i):
+        if i % 2 == 0 and i > 0:
+            bd.advance_outer()
+        return bd.step()
+
+    for i in range(args.warmup):
+        one_step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        norms = one_step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        assert norms.numel() == B
+        print(json.dumps({
+            "metric": "Newton steps/sec on dense KKT n=1024 m=256, batch of 256 instances",
+            "value": args.steps * B / elapsed, "unit": "instance Newton steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": args.workload, "n": n, "m": m, "instances": B,
+                       "instances_per_gpu": bd.hi - bd.lo, "newton_type": "Full",
+                       "collective": "all_gather(256 residual norms)" if world > 1 else "none"},
+            "roofline": None, "cpu_baseline": None,
+        }), flush=True)
+    bd.close()
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def main():
@@ -97,6 +164,8 @@ def main():
 
     wl = WORKLOADS[args.workload]
     n, m = wl["n"], wl["m"]
+    if wl["batch"] > 1:
+        return bench_batched(args, wl, rank, local_rank, world, dist, torch)
     problem = problems.dense_qp(n, m, seed=rank)
     x0, y0 = np.zeros(n), np.zeros(m)
     dn = DeviceNewton(problem, "Full", x0, y0, 1.0, 1.0, device=local_rank)
@@ -111,7 +180,7 @@ def main():
         dn.step()
         dn.residual_norm(norms_local.data_ptr())
         if dist is not None:
-            dist.all_gather_into_tensor(norms_all, norms_local)
+            dist.all_gather_into_tensor(norms_all, norms_local)  # the one collective / step
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -167,7 +236,7 @@ def main():
             roof = dict(
                 bound="mfma", kernel="k_ldlt_update", achieved=achieved,
                 peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP64_MFMA_TFLOPS,
-                traffic=None,
+                traffic=pmc_traffic("k_ldlt_update"),
                 launches_per_step=pr["update_launches"] / args.steps,
                 avg_launch_us=1e3 * pr["update_ms"] / pr["update_launches"],
                 flops_per_step=pr["update_flops"] / args.steps,
