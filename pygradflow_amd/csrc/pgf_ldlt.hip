@@ -267,22 +267,24 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
 
 // BM x BN = tile (rows x columns); BK = K-chunk staged per barrier pair; 4 wavefronts as
 // 2 x 2, each (BM/2) x (BN/2) = TM x TN MFMA tiles.  LDS rows are padded to BK + 2 doubles.
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, int WR = 2, int WC = 2>
 __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, const int j0,
                                             double *__restrict__ K, int64_t ldk,
                                             const double *__restrict__ W, int64_t ldw, int N,
                                             int nrows, int colEnd, int kc0, int KB) {
-  constexpr int TM = BM / 32, TN = BN / 32;  // MFMA tiles per wavefront
-  constexpr int WM = BM / 2, WN = BN / 2;    // rows / columns per wavefront
+  constexpr int NT = 64 * WR * WC;           // threads per workgroup
+  constexpr int WM = BM / WR, WN = BN / WC;  // rows / columns per wavefront
+  constexpr int TM = WM / 16, TN = WN / 16;  // MFMA tiles per wavefront
   constexpr int LD = BK + 2;
   constexpr int PPR = BK / 2;                // 16-byte pieces per row
-  constexpr int PA = BM * PPR / 256, PB = BN * PPR / 256;
+  constexpr int PA = BM * PPR / NT, PB = BN * PPR / NT;
+  static_assert(PA >= 1 && PB >= 1, "tile too small for the workgroup");
   double(*As)[LD] = reinterpret_cast<double(*)[LD]>(smem);
   double(*Bs)[LD] = reinterpret_cast<double(*)[LD]>(smem + BM * LD * 8);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WC, wc = wave % WC;
   const int l15 = lane & 15, l4 = lane >> 4;
 
   // accumulators <- C tile (entries above the diagonal / outside the region are never
@@ -308,7 +310,7 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, c
   auto fetch = [&](int kk) {
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
-      const int p = q * 256 + tid;
+      const int p = q * NT + tid;
       const int row = p / PPR, kofs = (p % PPR) * 2;
       const int gi = i0 + row;
       double2_t va = (double2_t){0.0, 0.0};
@@ -317,7 +319,7 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, c
     }
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
-      const int p = q * 256 + tid;
+      const int p = q * NT + tid;
       const int row = p / PPR, kofs = (p % PPR) * 2;
       const int gj = j0 + row;
       double2_t vb = (double2_t){0.0, 0.0};
@@ -331,12 +333,12 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, c
     // wavefront wait for the prefetch before it starts the current chunk's MFMAs
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
-      const int p = q * 256 + tid;
+      const int p = q * NT + tid;
       *reinterpret_cast<double2_t *>(&As[p / PPR][(p % PPR) * 2]) = -pa[q];
     }
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
-      const int p = q * 256 + tid;
+      const int p = q * NT + tid;
       *reinterpret_cast<double2_t *>(&Bs[p / PPR][(p % PPR) * 2]) = pb[q];
     }
   };
@@ -377,16 +379,15 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, c
   }
 }
 
-template <int BM, int BN, int BK>
-__global__ __launch_bounds__(256) void k_ldlt_update(double *__restrict__ K, int64_t ldk,
-                                                     const double *__restrict__ W, int64_t ldw,
-                                                     int N, int nrows, int row0, int col0,
-                                                     int colEnd, int kc0, int KB) {
+template <int BM, int BN, int BK, int WR = 2, int WC = 2>
+__global__ __launch_bounds__(64 * WR * WC) void k_ldlt_update(
+    double *__restrict__ K, int64_t ldk, const double *__restrict__ W, int64_t ldw, int N,
+    int nrows, int row0, int col0, int colEnd, int kc0, int KB) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * (BK + 2) * 8];
   const int i0 = row0 + blockIdx.y * BM;
   const int j0 = col0 + blockIdx.x * BN;
   if (j0 > i0 + BM - 1) return;  // tile entirely above the diagonal
-  update_tile<BM, BN, BK>(smem, i0, j0, K, ldk, W, ldw, N, nrows, colEnd, kc0, KB);
+  update_tile<BM, BN, BK, WR, WC>(smem, i0, j0, K, ldk, W, ldw, N, nrows, colEnd, kc0, KB);
 }
 
 template <int NB>
@@ -793,18 +794,20 @@ hipError_t ldlt_bench_update(int N, int KB, int variant, int reps, double *ms_ou
   // region: rows/cols [KB, KB + N), L panel in columns [0, KB)
   const int Nt = N + KB;
   auto launch = [&]() {
-#define PGF_LAUNCH_VARIANT(BM_, BN_, BK_)                                                       \
-  hipLaunchKernelGGL((k_ldlt_update<BM_, BN_, BK_>), dim3((N + BN_ - 1) / BN_, (N + BM_ - 1) / BM_), \
-                     dim3(256), 0, s, f.K, f.ldk, f.W, (int64_t)KB, Nt, Nt, KB, KB, Nt, 0, KB)
+#define PGF_LAUNCH_VARIANT(BM_, BN_, BK_, WR_, WC_)                                          \
+  hipLaunchKernelGGL((k_ldlt_update<BM_, BN_, BK_, WR_, WC_>),                                  \
+                     dim3((N + BN_ - 1) / BN_, (N + BM_ - 1) / BM_), dim3(64 * WR_ * WC_), 0, s, \
+                     f.K, f.ldk, f.W, (int64_t)KB, Nt, Nt, KB, KB, Nt, 0, KB)
     switch (variant) {
-      case 0: PGF_LAUNCH_VARIANT(64, 64, 16); break;
-      case 1: PGF_LAUNCH_VARIANT(64, 64, 32); break;
-      case 2: PGF_LAUNCH_VARIANT(128, 64, 16); break;
-      case 3: PGF_LAUNCH_VARIANT(64, 128, 16); break;
-      case 4: PGF_LAUNCH_VARIANT(128, 128, 16); break;
-      case 5: PGF_LAUNCH_VARIANT(128, 64, 32); break;
-      case 6: PGF_LAUNCH_VARIANT(128, 128, 32); break;
-      default: PGF_LAUNCH_VARIANT(64, 64, 16); break;
+      case 0: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2); break;
+      case 1: PGF_LAUNCH_VARIANT(128, 128, 16, 2, 4); break;
+      case 2: PGF_LAUNCH_VARIANT(128, 128, 16, 4, 2); break;
+      case 3: PGF_LAUNCH_VARIANT(128, 128, 16, 4, 4); break;
+      case 4: PGF_LAUNCH_VARIANT(128, 128, 32, 4, 4); break;
+      case 5: PGF_LAUNCH_VARIANT(128, 64, 16, 4, 2); break;
+      case 6: PGF_LAUNCH_VARIANT(256, 128, 16, 4, 4); break;
+      case 7: PGF_LAUNCH_VARIANT(128, 128, 16, 2, 2); break;
+      default: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2); break;
     }
 #undef PGF_LAUNCH_VARIANT
   };
