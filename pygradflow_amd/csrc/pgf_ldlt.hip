@@ -267,7 +267,7 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
 
 // BM x BN = tile (rows x columns); BK = K-chunk staged per barrier pair; 4 wavefronts as
 // 2 x 2, each (BM/2) x (BN/2) = TM x TN MFMA tiles.  LDS rows are padded to BK + 2 doubles.
-template <int BM, int BN, int BK, int WR = 2, int WC = 2>
+template <int BM, int BN, int BK, int WR = 2, int WC = 2, bool DB = false>
 __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, const int j0,
                                             double *__restrict__ K, int64_t ldk,
                                             const double *__restrict__ W, int64_t ldw, int N,
@@ -279,8 +279,7 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, c
   constexpr int PPR = BK / 2;                // 16-byte pieces per row
   constexpr int PA = BM * PPR / NT, PB = BN * PPR / NT;
   static_assert(PA >= 1 && PB >= 1, "tile too small for the workgroup");
-  double(*As)[LD] = reinterpret_cast<double(*)[LD]>(smem);
-  double(*Bs)[LD] = reinterpret_cast<double(*)[LD]>(smem + BM * LD * 8);
+  constexpr int STAGE = (BM + BN) * LD * 8;  // bytes of one LDS stage (A then B)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -328,7 +327,9 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, c
       pb[q] = vb;
     }
   };
-  auto stage = [&]() {
+  auto stage = [&](int buf) {
+    double(*As)[LD] = reinterpret_cast<double(*)[LD]>(smem + buf * STAGE);
+    double(*Bs)[LD] = reinterpret_cast<double(*)[LD]>(smem + buf * STAGE + BM * LD * 8);
     // negate here, not at the fetch: touching the loaded value there would make the
     // wavefront wait for the prefetch before it starts the current chunk's MFMAs
 #pragma unroll
@@ -342,13 +343,9 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, c
       *reinterpret_cast<double2_t *>(&Bs[p / PPR][(p % PPR) * 2]) = pb[q];
     }
   };
-
-  fetch(0);
-  for (int kk = 0; kk < KB; kk += BK) {
-    __syncthreads();  // previous chunk's fragment reads are done
-    stage();
-    __syncthreads();
-    if (kk + BK < KB) fetch(kk + BK);
+  auto compute = [&](int buf) {
+    double(*As)[LD] = reinterpret_cast<double(*)[LD]>(smem + buf * STAGE);
+    double(*Bs)[LD] = reinterpret_cast<double(*)[LD]>(smem + buf * STAGE + BM * LD * 8);
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 4) {
       double a[TM], b[TN];
@@ -361,6 +358,31 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, c
 #pragma unroll
         for (int nj = 0; nj < TN; ++nj)
           acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
+    }
+  };
+
+  fetch(0);
+  if (DB) {
+    // two LDS stages, ONE barrier per chunk: chunk c is computed from stage c&1 while the
+    // prefetched chunk c+1 is written to the other stage (last read one iteration ago)
+    stage(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kk = 0; kk < KB; kk += BK) {
+      const bool more = kk + BK < KB;
+      if (more) fetch(kk + BK);
+      compute(cur);
+      if (more) stage(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    for (int kk = 0; kk < KB; kk += BK) {
+      __syncthreads();  // previous chunk's fragment reads are done
+      stage(0);
+      __syncthreads();
+      if (kk + BK < KB) fetch(kk + BK);
+      compute(0);
     }
   }
 
@@ -379,15 +401,15 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, c
   }
 }
 
-template <int BM, int BN, int BK, int WR = 2, int WC = 2>
+template <int BM, int BN, int BK, int WR = 2, int WC = 2, bool DB = false>
 __global__ __launch_bounds__(64 * WR * WC) void k_ldlt_update(
     double *__restrict__ K, int64_t ldk, const double *__restrict__ W, int64_t ldw, int N,
     int nrows, int row0, int col0, int colEnd, int kc0, int KB) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * (BK + 2) * 8];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(DB ? 2 : 1) * (BM + BN) * (BK + 2) * 8];
   const int i0 = row0 + blockIdx.y * BM;
   const int j0 = col0 + blockIdx.x * BN;
   if (j0 > i0 + BM - 1) return;  // tile entirely above the diagonal
-  update_tile<BM, BN, BK, WR, WC>(smem, i0, j0, K, ldk, W, ldw, N, nrows, colEnd, kc0, KB);
+  update_tile<BM, BN, BK, WR, WC, DB>(smem, i0, j0, K, ldk, W, ldw, N, nrows, colEnd, kc0, KB);
 }
 
 template <int NB>
@@ -794,20 +816,21 @@ hipError_t ldlt_bench_update(int N, int KB, int variant, int reps, double *ms_ou
   // region: rows/cols [KB, KB + N), L panel in columns [0, KB)
   const int Nt = N + KB;
   auto launch = [&]() {
-#define PGF_LAUNCH_VARIANT(BM_, BN_, BK_, WR_, WC_)                                          \
-  hipLaunchKernelGGL((k_ldlt_update<BM_, BN_, BK_, WR_, WC_>),                                  \
+#define PGF_LAUNCH_VARIANT(BM_, BN_, BK_, WR_, WC_, DB_)                                     \
+  hipLaunchKernelGGL((k_ldlt_update<BM_, BN_, BK_, WR_, WC_, DB_>),                             \
                      dim3((N + BN_ - 1) / BN_, (N + BM_ - 1) / BM_), dim3(64 * WR_ * WC_), 0, s, \
                      f.K, f.ldk, f.W, (int64_t)KB, Nt, Nt, KB, KB, Nt, 0, KB)
     switch (variant) {
-      case 0: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2); break;
-      case 1: PGF_LAUNCH_VARIANT(128, 128, 16, 2, 4); break;
-      case 2: PGF_LAUNCH_VARIANT(128, 128, 16, 4, 2); break;
-      case 3: PGF_LAUNCH_VARIANT(128, 128, 16, 4, 4); break;
-      case 4: PGF_LAUNCH_VARIANT(128, 128, 32, 4, 4); break;
-      case 5: PGF_LAUNCH_VARIANT(128, 64, 16, 4, 2); break;
-      case 6: PGF_LAUNCH_VARIANT(256, 128, 16, 4, 4); break;
-      case 7: PGF_LAUNCH_VARIANT(128, 128, 16, 2, 2); break;
-      default: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2); break;
+      case 0: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2, false); break;
+      case 1: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2, true); break;
+      case 2: PGF_LAUNCH_VARIANT(128, 128, 16, 4, 4, false); break;
+      case 3: PGF_LAUNCH_VARIANT(128, 128, 16, 4, 4, true); break;
+      case 4: PGF_LAUNCH_VARIANT(128, 128, 32, 4, 4, true); break;
+      case 5: PGF_LAUNCH_VARIANT(128, 128, 16, 2, 4, true); break;
+      case 6: PGF_LAUNCH_VARIANT(128, 128, 32, 2, 4, true); break;
+      case 7: PGF_LAUNCH_VARIANT(128, 64, 16, 4, 2, true); break;
+      case 8: PGF_LAUNCH_VARIANT(256, 128, 16, 4, 4, true); break;
+      default: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2, false); break;
     }
 #undef PGF_LAUNCH_VARIANT
   };
