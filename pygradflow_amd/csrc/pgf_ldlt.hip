@@ -267,7 +267,7 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
 
 // BM x BN = tile (rows x columns); BK = K-chunk staged per barrier pair; 4 wavefronts as
 // 2 x 2, each (BM/2) x (BN/2) = TM x TN MFMA tiles.  LDS rows are padded to BK + 2 doubles.
-template <int BM, int BN, int BK, int WR = 2, int WC = 2, bool DB = false>
+template <int BM, int BN, int BK, int WR = 2, int WC = 2, int DB = 0>
 __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, const int j0,
                                             double *__restrict__ K, int64_t ldk,
                                             const double *__restrict__ W, int64_t ldw, int N,
@@ -305,8 +305,9 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, c
   }
 
   // staging map: piece p = q*256 + tid -> row p / PPR, two doubles at column (p % PPR)*2
-  double2_t pa[PA], pb[PB];
-  auto fetch = [&](int kk) {
+  double2_t pa2[2][PA], pb2[2][PB];
+  auto fetch = [&](int kk, int rs = 0) {
+    double2_t *pa = pa2[rs], *pb = pb2[rs];
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
       const int p = q * NT + tid;
@@ -327,7 +328,8 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, c
       pb[q] = vb;
     }
   };
-  auto stage = [&](int buf) {
+  auto stage = [&](int buf, int rs = 0) {
+    double2_t *pa = pa2[rs], *pb = pb2[rs];
     double(*As)[LD] = reinterpret_cast<double(*)[LD]>(smem + buf * STAGE);
     double(*Bs)[LD] = reinterpret_cast<double(*)[LD]>(smem + buf * STAGE + BM * LD * 8);
     // negate here, not at the fetch: touching the loaded value there would make the
@@ -362,7 +364,21 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, c
   };
 
   fetch(0);
-  if (DB) {
+  if (DB == 2) {
+    // two LDS stages and TWO chunks in flight (two register sets): the loads of chunk c+2
+    // are issued before chunk c is computed, so a fetch has two compute phases to land
+    const int nc = KB / BK;
+    if (nc > 1) fetch(BK, 1);
+    stage(0, 0);
+    __syncthreads();
+#pragma unroll 2
+    for (int c = 0; c < nc; ++c) {
+      if (c + 2 < nc) fetch((c + 2) * BK, c & 1);  // set c&1 was staged one iteration ago
+      compute(c & 1);
+      if (c + 1 < nc) stage((c + 1) & 1, (c + 1) & 1);
+      __syncthreads();
+    }
+  } else if (DB) {
     // two LDS stages, ONE barrier per chunk: chunk c is computed from stage c&1 while the
     // prefetched chunk c+1 is written to the other stage (last read one iteration ago)
     stage(0);
@@ -401,7 +417,7 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, c
   }
 }
 
-template <int BM, int BN, int BK, int WR = 2, int WC = 2, bool DB = false>
+template <int BM, int BN, int BK, int WR = 2, int WC = 2, int DB = 0>
 __global__ __launch_bounds__(64 * WR * WC) void k_ldlt_update(
     double *__restrict__ K, int64_t ldk, const double *__restrict__ W, int64_t ldw, int N,
     int nrows, int row0, int col0, int colEnd, int kc0, int KB) {
@@ -821,16 +837,16 @@ hipError_t ldlt_bench_update(int N, int KB, int variant, int reps, double *ms_ou
                      dim3((N + BN_ - 1) / BN_, (N + BM_ - 1) / BM_), dim3(64 * WR_ * WC_), 0, s, \
                      f.K, f.ldk, f.W, (int64_t)KB, Nt, Nt, KB, KB, Nt, 0, KB)
     switch (variant) {
-      case 0: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2, false); break;
-      case 1: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2, true); break;
-      case 2: PGF_LAUNCH_VARIANT(128, 128, 16, 4, 4, false); break;
-      case 3: PGF_LAUNCH_VARIANT(128, 128, 16, 4, 4, true); break;
-      case 4: PGF_LAUNCH_VARIANT(128, 128, 32, 4, 4, true); break;
-      case 5: PGF_LAUNCH_VARIANT(128, 128, 16, 2, 4, true); break;
-      case 6: PGF_LAUNCH_VARIANT(128, 128, 32, 2, 4, true); break;
-      case 7: PGF_LAUNCH_VARIANT(128, 64, 16, 4, 2, true); break;
-      case 8: PGF_LAUNCH_VARIANT(256, 128, 16, 4, 4, true); break;
-      default: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2, false); break;
+      case 0: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2, 0); break;
+      case 1: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2, 2); break;
+      case 2: PGF_LAUNCH_VARIANT(128, 128, 16, 4, 4, 1); break;
+      case 3: PGF_LAUNCH_VARIANT(128, 128, 16, 4, 4, 2); break;
+      case 4: PGF_LAUNCH_VARIANT(128, 128, 32, 4, 4, 2); break;
+      case 5: PGF_LAUNCH_VARIANT(128, 128, 16, 2, 4, 2); break;
+      case 6: PGF_LAUNCH_VARIANT(128, 64, 16, 4, 2, 2); break;
+      case 7: PGF_LAUNCH_VARIANT(128, 64, 16, 2, 2, 2); break;
+      case 8: PGF_LAUNCH_VARIANT(256, 128, 16, 4, 4, 2); break;
+      default: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2, 0); break;
     }
 #undef PGF_LAUNCH_VARIANT
   };
