@@ -549,6 +549,72 @@ __global__ __launch_bounds__(64) void k_trsv_bwd(const double *__restrict__ K, i
   if (live) z[t] = (s0 + s1) + (s2 + s3);
 }
 
+// Backward solve L^T s = w, one launch per SUPER-row super-block (4 x 64 sub-blocks), one
+// wavefront per workgroup.  Every workgroup walks the super-block's sub-blocks from last to
+// first: transposed 64 x 64 triangular solve by wave-level substitution (v_readlane
+// broadcasts), then the solved sub-block is published to LDS and folded (rolled loop, LDS
+// broadcast reads) into the entries it feeds -- the earlier sub-blocks of the same
+// super-block (redundantly in every workgroup) and this workgroup's own 64 entries to the
+// left of the super-block.  4x fewer launches than one per 64-block and compact code.
+template <int SUPER>
+__global__ __launch_bounds__(64) void k_trsv_bwd_super(const double *__restrict__ K, int64_t ldk,
+                                                        double *__restrict__ z,
+                                                        double *__restrict__ x, int N, int c0) {
+  constexpr int NSUB = SUPER / 64;
+  __shared__ double zs[SUPER];  // work entries of the super-block
+  __shared__ double xs[64];     // solved sub-block
+  const int lane = threadIdx.x;
+  const int width = min(SUPER, N - c0);
+  const int nsub = (width + 63) / 64;
+  for (int q = 0; q < NSUB; ++q) {
+    const int g = c0 + q * 64 + lane;
+    zs[q * 64 + lane] = (q * 64 + lane < width) ? z[g] : 0.0;
+  }
+  // this workgroup's own entry to the left of the super-block
+  const int t = blockIdx.x * 64 + lane;
+  const bool live = (c0 > 0) && t < c0;
+  double zext = live ? z[t] : 0.0;
+  for (int sb = nsub - 1; sb >= 0; --sb) {
+    const int b0 = c0 + sb * 64;
+    const int nb = min(64, N - b0);
+    double lcol[64];  // L[b0 + j][b0 + lane] for j > lane (row j is contiguous across lanes)
+#pragma unroll
+    for (int j = 0; j < 64; ++j)
+      lcol[j] = (j < nb && j > lane) ? K[(int64_t)(b0 + j) * ldk + b0 + lane] : 0.0;
+    double xv = zs[sb * 64 + lane];
+#pragma unroll
+    for (int j = 63; j > 0; --j) xv = fma(-lcol[j], lane_bcast(xv, j), xv);
+    xs[lane] = xv;
+    if (blockIdx.x == 0 && lane < nb) x[b0 + lane] = xv;
+    // fold into the earlier sub-blocks of this super-block and into the own outside entry
+    for (int q = 0; q < sb; ++q) {
+      const double *cp = K + (int64_t)b0 * ldk + c0 + q * 64 + lane;
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+      for (int j = 0; j < 64; j += 2) {
+        const double l0 = (j < nb) ? cp[(int64_t)j * ldk] : 0.0;
+        const double l1 = (j + 1 < nb) ? cp[(int64_t)(j + 1) * ldk] : 0.0;
+        s0 = fma(l0, xs[j], s0);
+        s1 = fma(l1, xs[j + 1], s1);
+      }
+      zs[q * 64 + lane] -= s0 + s1;
+    }
+    if (live) {
+      const double *cp = K + (int64_t)b0 * ldk + t;
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+      for (int j = 0; j < 64; j += 2) {
+        const double l0 = (j < nb) ? cp[(int64_t)j * ldk] : 0.0;
+        const double l1 = (j + 1 < nb) ? cp[(int64_t)(j + 1) * ldk] : 0.0;
+        s0 = fma(l0, xs[j], s0);
+        s1 = fma(l1, xs[j + 1], s1);
+      }
+      zext -= s0 + s1;
+    }
+  }
+  if (live) z[t] = zext;
+}
+
 __global__ void k_vec_scale(double *__restrict__ z, const double *__restrict__ dinv, int N) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) z[i] *= dinv[i];
@@ -780,11 +846,12 @@ hipError_t ldlt_backsolve_async(DenseLdlt &f, const double *w, double *sol) {
   hipStream_t s = f.stream;
   if (N == 0) return hipSuccess;
   hipLaunchKernelGGL(k_vec_copy_strided, dim3((N + 255) / 256), dim3(256), 0, s, f.zwork, w, N);
-  const int last = ((N - 1) / PGF_NB) * PGF_NB;
-  for (int c0 = last; c0 >= 0; c0 -= PGF_NB) {
+  constexpr int SUPER = 256;
+  const int last = ((N - 1) / SUPER) * SUPER;
+  for (int c0 = last; c0 >= 0; c0 -= SUPER) {
     const int g = c0 > 0 ? (c0 + 63) / 64 : 1;
-    hipLaunchKernelGGL(k_trsv_bwd<PGF_NB>, dim3(g), dim3(64), 0, s, f.K, f.ldk, f.zwork, sol, N,
-                       c0);
+    hipLaunchKernelGGL(k_trsv_bwd_super<SUPER>, dim3(g), dim3(64), 0, s, f.K, f.ldk, f.zwork, sol,
+                       N, c0);
   }
   return hipGetLastError();
 }
