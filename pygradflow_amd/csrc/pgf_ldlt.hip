@@ -549,70 +549,70 @@ __global__ __launch_bounds__(64) void k_trsv_bwd(const double *__restrict__ K, i
   if (live) z[t] = (s0 + s1) + (s2 + s3);
 }
 
-// Backward solve L^T s = w, one launch per SUPER-row super-block (4 x 64 sub-blocks), one
-// wavefront per workgroup.  Every workgroup walks the super-block's sub-blocks from last to
-// first: transposed 64 x 64 triangular solve by wave-level substitution (v_readlane
-// broadcasts), then the solved sub-block is published to LDS and folded (rolled loop, LDS
-// broadcast reads) into the entries it feeds -- the earlier sub-blocks of the same
-// super-block (redundantly in every workgroup) and this workgroup's own 64 entries to the
-// left of the super-block.  4x fewer launches than one per 64-block and compact code.
+// Backward solve L^T s = w, one launch per SUPER-row super-block (4 x 64 sub-blocks),
+// 4 wavefronts per workgroup.  Sub-blocks are walked from last to first.  Per sub-block:
+//   * every wavefront first issues the 64 loads of the block-row segment it will fold
+//     (wavefront q < sb: the earlier sub-block q of this super-block, redundantly in every
+//     workgroup; wavefront 3: this workgroup's own 64 entries left of the super-block) --
+//     these do not depend on the solve, so their latency hides behind it;
+//   * wavefront 0 solves the transposed 64 x 64 triangular system by substitution
+//     (v_readlane broadcasts) and publishes the solved sub-block in LDS;
+//   * after a barrier each wavefront folds the solved values into its target entries.
+// 4x fewer launches than one per 64-block, and no load batch on the critical path except
+// the diagonal block's.
 template <int SUPER>
-__global__ __launch_bounds__(64) void k_trsv_bwd_super(const double *__restrict__ K, int64_t ldk,
-                                                        double *__restrict__ z,
-                                                        double *__restrict__ x, int N, int c0) {
-  constexpr int NSUB = SUPER / 64;
+__global__ __launch_bounds__(256) void k_trsv_bwd_super(const double *__restrict__ K, int64_t ldk,
+                                                         double *__restrict__ z,
+                                                         double *__restrict__ x, int N, int c0) {
+  static_assert(SUPER == 256, "four sub-blocks, four wavefronts");
   __shared__ double zs[SUPER];  // work entries of the super-block
   __shared__ double xs[64];     // solved sub-block
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int width = min(SUPER, N - c0);
   const int nsub = (width + 63) / 64;
-  for (int q = 0; q < NSUB; ++q) {
-    const int g = c0 + q * 64 + lane;
-    zs[q * 64 + lane] = (q * 64 + lane < width) ? z[g] : 0.0;
-  }
-  // this workgroup's own entry to the left of the super-block
+  zs[tid] = (tid < width) ? z[c0 + tid] : 0.0;
+  // wavefront 3: this workgroup's own entry to the left of the super-block
   const int t = blockIdx.x * 64 + lane;
-  const bool live = (c0 > 0) && t < c0;
-  double zext = live ? z[t] : 0.0;
+  const bool ext_live = (wave == 3) && (c0 > 0) && t < c0;
+  double zext = ext_live ? z[t] : 0.0;
+  __syncthreads();
   for (int sb = nsub - 1; sb >= 0; --sb) {
     const int b0 = c0 + sb * 64;
     const int nb = min(64, N - b0);
-    double lcol[64];  // L[b0 + j][b0 + lane] for j > lane (row j is contiguous across lanes)
+    // fold operand of this wavefront: column segment L[b0 .. b0+63][target]
+    const bool in_fold = wave < sb;               // earlier sub-block `wave`
+    const bool do_fold = in_fold || ext_live;
+    const int tcol = in_fold ? (c0 + wave * 64 + lane) : t;
+    const double *cp = K + (int64_t)b0 * ldk + (do_fold ? tcol : 0);
+    double lv[64];
 #pragma unroll
-    for (int j = 0; j < 64; ++j)
-      lcol[j] = (j < nb && j > lane) ? K[(int64_t)(b0 + j) * ldk + b0 + lane] : 0.0;
-    double xv = zs[sb * 64 + lane];
+    for (int j = 0; j < 64; ++j) lv[j] = (do_fold && j < nb) ? cp[(int64_t)j * ldk] : 0.0;
+    if (wave == 0) {
+      double lcol[64];  // L[b0 + j][b0 + lane] for j > lane (row j contiguous across lanes)
 #pragma unroll
-    for (int j = 63; j > 0; --j) xv = fma(-lcol[j], lane_bcast(xv, j), xv);
-    xs[lane] = xv;
-    if (blockIdx.x == 0 && lane < nb) x[b0 + lane] = xv;
-    // fold into the earlier sub-blocks of this super-block and into the own outside entry
-    for (int q = 0; q < sb; ++q) {
-      const double *cp = K + (int64_t)b0 * ldk + c0 + q * 64 + lane;
-      double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-      for (int j = 0; j < 64; j += 2) {
-        const double l0 = (j < nb) ? cp[(int64_t)j * ldk] : 0.0;
-        const double l1 = (j + 1 < nb) ? cp[(int64_t)(j + 1) * ldk] : 0.0;
-        s0 = fma(l0, xs[j], s0);
-        s1 = fma(l1, xs[j + 1], s1);
-      }
-      zs[q * 64 + lane] -= s0 + s1;
+      for (int j = 0; j < 64; ++j)
+        lcol[j] = (j < nb && j > lane) ? K[(int64_t)(b0 + j) * ldk + b0 + lane] : 0.0;
+      double xv = zs[sb * 64 + lane];
+#pragma unroll
+      for (int j = 63; j > 0; --j) xv = fma(-lcol[j], lane_bcast(xv, j), xv);
+      xs[lane] = xv;
+      if (blockIdx.x == 0 && lane < nb) x[b0 + lane] = xv;
     }
-    if (live) {
-      const double *cp = K + (int64_t)b0 * ldk + t;
-      double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-      for (int j = 0; j < 64; j += 2) {
-        const double l0 = (j < nb) ? cp[(int64_t)j * ldk] : 0.0;
-        const double l1 = (j + 1 < nb) ? cp[(int64_t)(j + 1) * ldk] : 0.0;
-        s0 = fma(l0, xs[j], s0);
-        s1 = fma(l1, xs[j + 1], s1);
-      }
-      zext -= s0 + s1;
+    __syncthreads();
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 64; j += 4) {
+      s0 = fma(lv[j], xs[j], s0);
+      s1 = fma(lv[j + 1], xs[j + 1], s1);
+      s2 = fma(lv[j + 2], xs[j + 2], s2);
+      s3 = fma(lv[j + 3], xs[j + 3], s3);
     }
+    const double sum = (s0 + s1) + (s2 + s3);
+    if (in_fold) zs[wave * 64 + lane] -= sum;
+    if (ext_live) zext -= sum;
+    __syncthreads();
   }
-  if (live) z[t] = zext;
+  if (ext_live) z[t] = zext;
 }
 
 __global__ void k_vec_scale(double *__restrict__ z, const double *__restrict__ dinv, int N) {
@@ -850,7 +850,7 @@ hipError_t ldlt_backsolve_async(DenseLdlt &f, const double *w, double *sol) {
   const int last = ((N - 1) / SUPER) * SUPER;
   for (int c0 = last; c0 >= 0; c0 -= SUPER) {
     const int g = c0 > 0 ? (c0 + 63) / 64 : 1;
-    hipLaunchKernelGGL(k_trsv_bwd_super<SUPER>, dim3(g), dim3(64), 0, s, f.K, f.ldk, f.zwork, sol,
+    hipLaunchKernelGGL(k_trsv_bwd_super<SUPER>, dim3(g), dim3(256), 0, s, f.K, f.ldk, f.zwork, sol,
                        N, c0);
   }
   return hipGetLastError();
