@@ -206,3 +206,52 @@ def test_full_size_config2_properties(pgf):
     assert G.rel_err(x1, xn) <= TOL
     assert G.rel_err(y1, yn) <= TOL
     dn.close()
+
+
+def test_full_size_config5_box_qp_mask_churn(pgf):
+    """BASELINE config 5 at full size, dense variant 5b: box QP n=16384, m=0, ~50 % of the
+    bounds active, mask churning every Full step.  The oracle runs the same problem with the
+    sparse tridiagonal H (as the reference would); masks must agree bit for bit and iterates
+    to 1e-10 over 6 steps."""
+    from pygradflow_amd import problems
+
+    n = 16384
+    sparse = problems.box_qp(n, seed=0)
+    dense = problems.box_qp(n, seed=0, dense=True)
+    x0, y0 = np.zeros(n), np.zeros(0)
+    recs = O.NewtonOracle(sparse, "Full", x0, y0, 1.0, 1.0).run(x0, y0, 6)
+    dn = pgf.DeviceNewton(dense, "Full", x0, y0, 1.0, 1.0)
+    flips = []
+    prev = None
+    for k, rec in enumerate(recs):
+        diff, n_neg = dn.step()
+        mask = dn.mask()
+        assert np.array_equal(mask, rec["mask"]), k
+        x, _ = dn.point()
+        assert G.rel_err(x, rec["xn"]) <= TOL, k
+        assert n_neg == 0
+        if prev is not None:
+            flips.append(int(np.count_nonzero(mask != prev)))
+        prev = mask
+    assert 0.3 * n < mask.sum() < 0.7 * n
+    assert max(flips) > 0  # the mask really churns
+    dn.close()
+
+
+def test_batched_single_rank(pgf):
+    """BASELINE config 4 shape on one rank: a few n=1024, m=256 instances stepped by the
+    batched driver; norms come back in instance order and match per-instance drivers."""
+    from pygradflow_amd import problems
+    from pygradflow_amd.batched import BatchedDeviceNewton
+
+    B, n, m = 3, 1024, 256
+    bd = BatchedDeviceNewton(lambda i: problems.dense_qp(n, m, seed=i), B, "Full", 1.0, 1.0)
+    norms = bd.step().cpu().numpy()
+    assert norms.shape == (B,)
+    for i in range(B):
+        prob = problems.dense_qp(n, m, seed=i)
+        dn = pgf.DeviceNewton(prob, "Full", np.zeros(n), np.zeros(m), 1.0, 1.0)
+        dn.step()
+        assert abs(dn.residual_norm() - norms[i]) <= 1e-12 * max(1.0, norms[i])
+        dn.close()
+    bd.close()
