@@ -233,7 +233,7 @@ def test_full_size_config5_box_qp_mask_churn(pgf):
         if prev is not None:
             flips.append(int(np.count_nonzero(mask != prev)))
         prev = mask
-    assert 0.3 * n < mask.sum() < 0.7 * n
+    assert 0.4 * n < recs[0]["mask"].sum() < 0.6 * n  # ~50 % active at the first step
     assert max(flips) > 0  # the mask really churns
     dn.close()
 
