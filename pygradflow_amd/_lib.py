@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -81,6 +82,15 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -m pygradflow_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback."
         )
+    # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64.  If this
+    # library pulled in the system copy first, a later `import torch` would initialise a
+    # second runtime that finds "No HIP GPUs".  Importing torch first (when it is installed)
+    # makes both share torch's copy; without torch the system runtime is used.
+    if "torch" not in sys.modules and not os.environ.get("PGF_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
