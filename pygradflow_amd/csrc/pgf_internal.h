@@ -32,6 +32,8 @@ struct DenseLdlt {
   double *dvec = nullptr;   // D
   double *dinv = nullptr;   // 1 / D
   double *zwork = nullptr;  // solve work vector (Nmax)
+  double *Linv = nullptr;   // inverse of every 64 x 64 diagonal block of L, [block][row][64]
+  double *LinvT = nullptr;  // the transposes
   int *flags = nullptr;     // [0] zero-pivot flag, [1] negative pivots
   int *h_flags = nullptr;   // pinned host mirror
   hipStream_t stream = nullptr;

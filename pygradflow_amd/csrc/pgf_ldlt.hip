@@ -549,24 +549,62 @@ __global__ __launch_bounds__(64) void k_trsv_bwd(const double *__restrict__ K, i
   if (live) z[t] = (s0 + s1) + (s2 + s3);
 }
 
+// Inverse of every 64 x 64 unit-lower diagonal block of L (one workgroup = one wavefront per
+// block, all blocks in parallel, once per factorisation).  Lane c computes column c of
+// inv(L_bb) by right-looking substitution on e_c (the recurrence of a row of X L^T = I);
+// L_bb^T is broadcast from LDS.  Stored twice, inv(L_bb) and its transpose, both as
+// [block][row][64], so that forward and backward solves read coalesced rows.
+// The triangular solves then need no serial 63-step chain per block, only mat-vecs.
+__global__ __launch_bounds__(64) void k_inv_diag_blocks(const double *__restrict__ K, int64_t ldk,
+                                                        int N, double *__restrict__ Linv,
+                                                        double *__restrict__ LinvT) {
+  __shared__ __attribute__((aligned(16))) double Lt[64][64];  // Lt[t][j] = L_bb[j][t], j > t
+  const int lane = threadIdx.x;
+  const int b0 = blockIdx.x * 64;
+  const int nb = min(64, N - b0);
+  for (int idx = lane; idx < 64 * 64; idx += 64) {
+    const int j = idx >> 6, t = idx & 63;
+    Lt[t][j] = (j < nb && t < j) ? K[(int64_t)(b0 + j) * ldk + b0 + t] : 0.0;
+  }
+  __syncthreads();
+  double y[64];  // y[j] = inv(L_bb)[j][lane]
+#pragma unroll
+  for (int j = 0; j < 64; ++j) y[j] = (j == lane) ? 1.0 : 0.0;
+#pragma unroll
+  for (int t = 0; t < 63; ++t) {
+    const double yt = y[t];
+#pragma unroll
+    for (int j = t + 1; j < 64; ++j) y[j] = fma(-yt, Lt[t][j], y[j]);
+  }
+  double *o = Linv + (size_t)blockIdx.x * 4096;
+  double *ot = LinvT + (size_t)blockIdx.x * 4096;
+#pragma unroll
+  for (int j = 0; j < 64; ++j) o[j * 64 + lane] = y[j];  // row j of inv(L_bb), coalesced
+  // transpose through LDS (Lt is free now): row `lane` of the transpose = column written
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 64; ++j) Lt[lane][j] = y[j];         // Lt[c][j] = inv[j][c]
+  __syncthreads();
+  for (int idx = lane; idx < 64 * 64; idx += 64) ot[idx] = Lt[idx >> 6][idx & 63];
+}
+
 // Backward solve L^T s = w, one launch per SUPER-row super-block (4 x 64 sub-blocks),
 // 4 wavefronts per workgroup.  Sub-blocks are walked from last to first.  Per sub-block:
 //   * every wavefront first issues the 64 loads of the block-row segment it will fold
 //     (wavefront q < sb: the earlier sub-block q of this super-block, redundantly in every
-//     workgroup; wavefront 3: this workgroup's own 64 entries left of the super-block) --
-//     these do not depend on the solve, so their latency hides behind it;
-//   * wavefront 0 solves the transposed 64 x 64 triangular system by substitution
-//     (v_readlane broadcasts) and publishes the solved sub-block in LDS;
+//     workgroup; wavefront 3: this workgroup's own 64 entries left of the super-block);
+//   * wavefront 0 applies the transposed inverse of the diagonal block (a 64 x 64 mat-vec,
+//     operands prefetched one sub-block ahead) and publishes the solved sub-block in LDS;
 //   * after a barrier each wavefront folds the solved values into its target entries.
-// 4x fewer launches than one per 64-block, and no load batch on the critical path except
-// the diagonal block's.
 template <int SUPER>
 __global__ __launch_bounds__(256) void k_trsv_bwd_super(const double *__restrict__ K, int64_t ldk,
+                                                         const double *__restrict__ Linv,
                                                          double *__restrict__ z,
                                                          double *__restrict__ x, int N, int c0) {
   static_assert(SUPER == 256, "four sub-blocks, four wavefronts");
   __shared__ double zs[SUPER];  // work entries of the super-block
   __shared__ double xs[64];     // solved sub-block
+  __shared__ double rs[64];     // right-hand side of the sub-block being solved
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int width = min(SUPER, N - c0);
   const int nsub = (width + 63) / 64;
@@ -588,13 +626,21 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_super(const double *__restrict
 #pragma unroll
     for (int j = 0; j < 64; ++j) lv[j] = (do_fold && j < nb) ? cp[(int64_t)j * ldk] : 0.0;
     if (wave == 0) {
-      double lcol[64];  // L[b0 + j][b0 + lane] for j > lane (row j contiguous across lanes)
+      // x_i = sum_j inv(L_bb)[j][i] r_j : column i of the inverse, rows coalesced over lanes
+      const double *ip = Linv + (size_t)(b0 / 64) * 4096 + lane;
+      double iv[64];
 #pragma unroll
-      for (int j = 0; j < 64; ++j)
-        lcol[j] = (j < nb && j > lane) ? K[(int64_t)(b0 + j) * ldk + b0 + lane] : 0.0;
-      double xv = zs[sb * 64 + lane];
+      for (int j = 0; j < 64; ++j) iv[j] = ip[j * 64];
+      rs[lane] = zs[sb * 64 + lane];
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
-      for (int j = 63; j > 0; --j) xv = fma(-lcol[j], lane_bcast(xv, j), xv);
+      for (int j = 0; j < 64; j += 4) {
+        a0 = fma(iv[j], rs[j], a0);
+        a1 = fma(iv[j + 1], rs[j + 1], a1);
+        a2 = fma(iv[j + 2], rs[j + 2], a2);
+        a3 = fma(iv[j + 3], rs[j + 3], a3);
+      }
+      const double xv = (lane < nb) ? (a0 + a1) + (a2 + a3) : 0.0;
       xs[lane] = xv;
       if (blockIdx.x == 0 && lane < nb) x[b0 + lane] = xv;
     }
@@ -653,6 +699,8 @@ hipError_t ldlt_alloc(DenseLdlt &f, int Nmax, hipStream_t stream) {
   if ((e = hipMalloc(&f.dvec, rows * sizeof(double))) != hipSuccess) return e;
   if ((e = hipMalloc(&f.dinv, rows * sizeof(double))) != hipSuccess) return e;
   if ((e = hipMalloc(&f.zwork, rows * sizeof(double))) != hipSuccess) return e;
+  if ((e = hipMalloc(&f.Linv, (rows / 64 + 1) * 4096 * sizeof(double))) != hipSuccess) return e;
+  if ((e = hipMalloc(&f.LinvT, (rows / 64 + 1) * 4096 * sizeof(double))) != hipSuccess) return e;
   if ((e = hipMalloc(&f.flags, 4 * sizeof(int))) != hipSuccess) return e;
   if ((e = hipHostMalloc(&f.h_flags, 4 * sizeof(int))) != hipSuccess) return e;
   return hipSuccess;
@@ -664,6 +712,8 @@ void ldlt_free(DenseLdlt &f) {
   if (f.dvec) (void)hipFree(f.dvec);
   if (f.dinv) (void)hipFree(f.dinv);
   if (f.zwork) (void)hipFree(f.zwork);
+  if (f.Linv) (void)hipFree(f.Linv);
+  if (f.LinvT) (void)hipFree(f.LinvT);
   if (f.flags) (void)hipFree(f.flags);
   if (f.h_flags) (void)hipHostFree(f.h_flags);
   if (f.ev_panel) (void)hipEventDestroy(f.ev_panel);
@@ -826,6 +876,9 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
       }
     }
   }
+  if (N > 0)
+    hipLaunchKernelGGL(k_inv_diag_blocks, dim3((N + 63) / 64), dim3(64), 0, sA, f.K, f.ldk, N,
+                       f.Linv, f.LinvT);
   if (p) (void)hipEventRecord(p->factor_span.second, sA);
   e = hipMemcpyAsync(f.h_flags, f.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, sA);
   if (e != hipSuccess) return e;
@@ -850,8 +903,8 @@ hipError_t ldlt_backsolve_async(DenseLdlt &f, const double *w, double *sol) {
   const int last = ((N - 1) / SUPER) * SUPER;
   for (int c0 = last; c0 >= 0; c0 -= SUPER) {
     const int g = c0 > 0 ? (c0 + 63) / 64 : 1;
-    hipLaunchKernelGGL(k_trsv_bwd_super<SUPER>, dim3(g), dim3(256), 0, s, f.K, f.ldk, f.zwork, sol,
-                       N, c0);
+    hipLaunchKernelGGL(k_trsv_bwd_super<SUPER>, dim3(g), dim3(256), 0, s, f.K, f.ldk, f.Linv,
+                       f.zwork, sol, N, c0);
   }
   return hipGetLastError();
 }
