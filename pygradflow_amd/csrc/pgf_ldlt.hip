@@ -661,6 +661,79 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_super(const double *__restrict
   if (ext_live) z[t] = zext;
 }
 
+// Forward solve L y = b, mirror image of k_trsv_bwd_super: sub-blocks first to last;
+// wavefront 0 applies inv(L_bb) (rows of the stored transpose are coalesced over lanes) and
+// then folds into this workgroup's own 64 rows below the super-block; wavefront q > sb
+// folds into the later sub-block q of the same super-block (redundantly per workgroup).
+template <int SUPER>
+__global__ __launch_bounds__(256) void k_trsv_fwd_super(const double *__restrict__ K, int64_t ldk,
+                                                         const double *__restrict__ LinvT,
+                                                         double *__restrict__ z,
+                                                         double *__restrict__ x, int N, int c0) {
+  static_assert(SUPER == 256, "four sub-blocks, four wavefronts");
+  __shared__ double zs[SUPER];
+  __shared__ double xs[64];
+  __shared__ double rs[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int width = min(SUPER, N - c0);
+  const int nsub = (width + 63) / 64;
+  zs[tid] = (tid < width) ? z[c0 + tid] : 0.0;
+  // wavefront 0: this workgroup's own row below the super-block
+  const int r = c0 + SUPER + blockIdx.x * 64 + lane;
+  const bool ext_live = (wave == 0) && r < N;
+  double zext = ext_live ? z[r] : 0.0;
+  __syncthreads();
+  for (int sb = 0; sb < nsub; ++sb) {
+    const int b0 = c0 + sb * 64;
+    const int nb = min(64, N - b0);
+    const bool in_fold = (wave > sb) && (wave < nsub);  // later sub-block `wave`
+    const bool do_fold = in_fold || ext_live;
+    const int trow = in_fold ? (c0 + wave * 64 + lane) : r;
+    const bool row_ok = do_fold && trow < N;
+    const double *rp = K + (int64_t)(row_ok ? trow : 0) * ldk + b0;
+    double lv[64];
+#pragma unroll
+    for (int j = 0; j < 64; j += 2) {
+      double2_t v = (double2_t){0.0, 0.0};
+      if (row_ok) v = *reinterpret_cast<const double2_t *>(rp + j);
+      lv[j] = (j < nb) ? v.x : 0.0;
+      lv[j + 1] = (j + 1 < nb) ? v.y : 0.0;
+    }
+    if (wave == 0) {
+      const double *ip = LinvT + (size_t)(b0 / 64) * 4096 + lane;  // LinvT[j][i] = inv[i][j]
+      double iv[64];
+#pragma unroll
+      for (int j = 0; j < 64; ++j) iv[j] = ip[j * 64];
+      rs[lane] = zs[sb * 64 + lane];
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+      for (int j = 0; j < 64; j += 4) {
+        a0 = fma(iv[j], rs[j], a0);
+        a1 = fma(iv[j + 1], rs[j + 1], a1);
+        a2 = fma(iv[j + 2], rs[j + 2], a2);
+        a3 = fma(iv[j + 3], rs[j + 3], a3);
+      }
+      const double xv = (lane < nb) ? (a0 + a1) + (a2 + a3) : 0.0;
+      xs[lane] = xv;
+      if (blockIdx.x == 0 && lane < nb) x[b0 + lane] = xv;
+    }
+    __syncthreads();
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 64; j += 4) {
+      s0 = fma(lv[j], xs[j], s0);
+      s1 = fma(lv[j + 1], xs[j + 1], s1);
+      s2 = fma(lv[j + 2], xs[j + 2], s2);
+      s3 = fma(lv[j + 3], xs[j + 3], s3);
+    }
+    const double sum = (s0 + s1) + (s2 + s3);
+    if (in_fold) zs[wave * 64 + lane] -= sum;
+    if (ext_live) zext -= sum;
+    __syncthreads();
+  }
+  if (ext_live) z[r] = zext;
+}
+
 __global__ void k_vec_scale(double *__restrict__ z, const double *__restrict__ dinv, int N) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) z[i] *= dinv[i];
@@ -915,11 +988,11 @@ hipError_t ldlt_solve_async(DenseLdlt &f, const double *rhs, double *sol) {
   if (N == 0) return hipSuccess;
   // forward: L y = rhs  (work in zwork, y lands in sol)
   hipLaunchKernelGGL(k_vec_copy_strided, dim3((N + 255) / 256), dim3(256), 0, s, f.zwork, rhs, N);
-  for (int c0 = 0; c0 < N; c0 += PGF_NB) {
-    const int below = N - (c0 + PGF_NB);
+  for (int c0 = 0; c0 < N; c0 += 256) {
+    const int below = N - (c0 + 256);
     const int g = below > 0 ? (below + 63) / 64 : 1;
-    hipLaunchKernelGGL(k_trsv_fwd<PGF_NB>, dim3(g), dim3(64), 0, s, f.K, f.ldk, f.zwork, sol, N,
-                       c0);
+    hipLaunchKernelGGL(k_trsv_fwd_super<256>, dim3(g), dim3(256), 0, s, f.K, f.ldk, f.LinvT,
+                       f.zwork, sol, N, c0);
   }
   // diagonal: y <- D^-1 y
   hipLaunchKernelGGL(k_vec_scale, dim3((N + 255) / 256), dim3(256), 0, s, sol, f.dinv, N);
