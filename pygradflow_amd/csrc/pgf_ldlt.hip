@@ -7,11 +7,14 @@
 // the inertia the reference asks its linear solver for (num_neg_eigvals).
 //
 // Layout: lower triangle, row-major, row stride ldk (multiple of 16 doubles, so
-// every row starts on a 128-byte line).  Right-looking blocked algorithm:
-//   per 64-column panel   k_ldlt_diag   one workgroup, block in LDS
-//                         k_ldlt_trsm   one lane per panel row, row in VGPRs
-//                         k_ldlt_update 128x128 tiles, v_mfma_f64_16x16x4_f64
-// The trailing update is the FP64-MFMA-bound kernel the roofline is quoted on.
+// every row starts on a 128-byte line).  Two-level right-looking blocked algorithm
+// (outer block 256 columns, inner panels of 64):
+//   k_ldlt_panel        fused 64-column panel: 16-blocked LDL^T of the diagonal block +
+//                       TRSM of the workgroup's own 64 rows, all in LDS
+//   k_ldlt_update       trailing update, 64 x 64 tiles, v_mfma_f64_16x16x4_f64
+//                       (the FP64-MFMA-bound kernel the roofline is quoted on)
+//   k_inv_diag_blocks   inverse of every 64 x 64 diagonal block of L (once per factor)
+//   k_trsv_{fwd,bwd}_super  triangular solves, 256-row super-blocks per launch
 #include "pgf_internal.h"
 
 #include <algorithm>
@@ -467,88 +470,6 @@ __global__ __launch_bounds__(256, 2) void k_ldlt_panel_fused(
 }
 
 // ------------------------------------------------------------------ triangular solves
-// One launch per 64-row block.  Every workgroup (one wavefront) redundantly solves the
-// 64 x 64 diagonal system (lane broadcasts through v_readlane), then updates its own 64
-// entries of the work vector; workgroup 0 also publishes the block of the solution.
-// `z` is the work vector (updated in place below/above the block), `x` the solution.
-template <int NB>
-__global__ __launch_bounds__(64) void k_trsv_fwd(const double *__restrict__ K, int64_t ldk,
-                                                  double *__restrict__ z, double *__restrict__ x,
-                                                  int N, int c0) {
-  const int lane = threadIdx.x;
-  const int nb = min(NB, N - c0);
-  // L_kk row of this lane (strictly lower part)
-  double lrow[NB];
-  const double *lp = K + (int64_t)(c0 + lane) * ldk + c0;
-#pragma unroll
-  for (int j = 0; j < NB; ++j) lrow[j] = (lane < nb && j < lane) ? lp[j] : 0.0;
-  // this lane's row below the block (independent of the solve: issue the loads now)
-  const int r = c0 + NB + blockIdx.x * 64 + lane;
-  const bool live = r < N;
-  const double *rp = K + (int64_t)(live ? r : 0) * ldk + c0;
-  double urow[NB];
-#pragma unroll
-  for (int j = 0; j < NB; j += 2) {
-    double2_t v = (double2_t){0.0, 0.0};
-    if (live) v = *reinterpret_cast<const double2_t *>(rp + j);
-    urow[j] = v.x;
-    urow[j + 1] = v.y;
-  }
-  double s0 = live ? z[r] : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  double xv = (lane < nb) ? z[c0 + lane] : 0.0;
-#pragma unroll
-  for (int j = 0; j < NB - 1; ++j) {
-    const double xj = lane_bcast(xv, j);
-    xv = fma(-lrow[j], xj, xv);  // lrow[j] == 0 for lanes <= j
-  }
-  if (blockIdx.x == 0 && lane < nb) x[c0 + lane] = xv;
-#pragma unroll
-  for (int j = 0; j < NB; j += 4) {
-    s0 = fma(-urow[j], lane_bcast(xv, j), s0);
-    s1 = fma(-urow[j + 1], lane_bcast(xv, j + 1), s1);
-    s2 = fma(-urow[j + 2], lane_bcast(xv, j + 2), s2);
-    s3 = fma(-urow[j + 3], lane_bcast(xv, j + 3), s3);
-  }
-  if (live) z[r] = (s0 + s1) + (s2 + s3);
-}
-
-// Backward: L^T s = w.  Block solved with the transposed diagonal block; columns to the
-// left are updated with the block row L[c0.., t]^T (coalesced across lanes).
-template <int NB>
-__global__ __launch_bounds__(64) void k_trsv_bwd(const double *__restrict__ K, int64_t ldk,
-                                                  double *__restrict__ z, double *__restrict__ x,
-                                                  int N, int c0) {
-  const int lane = threadIdx.x;
-  const int nb = min(NB, N - c0);
-  double lcol[NB];  // L[c0 + j][c0 + lane] for j > lane
-#pragma unroll
-  for (int j = 0; j < NB; ++j)
-    lcol[j] = (j < nb && j > lane) ? K[(int64_t)(c0 + j) * ldk + c0 + lane] : 0.0;
-  // column t of the block row, to the left of the block (loads independent of the solve)
-  const int t = blockIdx.x * 64 + lane;
-  const bool live = (c0 > 0) && t < c0;
-  const double *cp = K + (int64_t)c0 * ldk + (live ? t : 0);
-  double ucol[NB];
-#pragma unroll
-  for (int j = 0; j < NB; ++j) ucol[j] = (live && j < nb) ? cp[(int64_t)j * ldk] : 0.0;
-  double s0 = live ? z[t] : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  double xv = (lane < nb) ? z[c0 + lane] : 0.0;
-#pragma unroll
-  for (int j = NB - 1; j > 0; --j) {
-    const double xj = lane_bcast(xv, j);
-    xv = fma(-lcol[j], xj, xv);  // lcol[j] == 0 for lanes >= j
-  }
-  if (blockIdx.x == 0 && lane < nb) x[c0 + lane] = xv;
-#pragma unroll
-  for (int j = 0; j < NB; j += 4) {
-    s0 = fma(-ucol[j], lane_bcast(xv, j), s0);
-    s1 = fma(-ucol[j + 1], lane_bcast(xv, j + 1), s1);
-    s2 = fma(-ucol[j + 2], lane_bcast(xv, j + 2), s2);
-    s3 = fma(-ucol[j + 3], lane_bcast(xv, j + 3), s3);
-  }
-  if (live) z[t] = (s0 + s1) + (s2 + s3);
-}
-
 // Inverse of every 64 x 64 unit-lower diagonal block of L (one workgroup = one wavefront per
 // block, all blocks in parallel, once per factorisation).  Lane c computes column c of
 // inv(L_bb) by right-looking substitution on e_c (the recurrence of a row of X L^T = I);
