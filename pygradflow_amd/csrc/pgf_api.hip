@@ -156,6 +156,10 @@ int pgf_destroy(pgf_handle h) {
     (void)hipEventDestroy(sp.first);
     (void)hipEventDestroy(sp.second);
   }
+  for (auto &sp : h->prof.factor_spans) {
+    (void)hipEventDestroy(sp.first);
+    (void)hipEventDestroy(sp.second);
+  }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return PGF_OK;
@@ -686,14 +690,13 @@ int pgf_profile_read(pgf_handle h, double *update_ms, int64_t *update_launches,
   }
   p.update_spans.clear();
   p.update_flops.clear();
-  if (p.factor_open) {
+  for (auto &sp : p.factor_spans) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, p.factor_span.first, p.factor_span.second) == hipSuccess)
-      p.acc_factor_ms += ms;
-    p.pool.push_back(p.factor_span.first);
-    p.pool.push_back(p.factor_span.second);
-    p.factor_open = false;
+    if (hipEventElapsedTime(&ms, sp.first, sp.second) == hipSuccess) p.acc_factor_ms += ms;
+    p.pool.push_back(sp.first);
+    p.pool.push_back(sp.second);
   }
+  p.factor_spans.clear();
   if (update_ms) *update_ms = p.acc_update_ms;
   if (update_launches) *update_launches = p.acc_update_launches;
   if (update_flops) *update_flops = p.acc_update_flops;

@@ -15,8 +15,7 @@ struct PgfProfile {
   std::vector<hipEvent_t> pool;  // recycled event pairs
   std::vector<std::pair<hipEvent_t, hipEvent_t>> update_spans;
   std::vector<double> update_flops;
-  std::pair<hipEvent_t, hipEvent_t> factor_span{nullptr, nullptr};
-  bool factor_open = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> factor_spans;
   double acc_update_ms = 0, acc_update_flops = 0, acc_factor_ms = 0;
   int64_t acc_update_launches = 0;
 };

@@ -779,14 +779,8 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
   if (e != hipSuccess) return e;
   PgfProfile *p = (f.prof && f.prof->enabled) ? f.prof : nullptr;
   if (p) {
-    if (p->factor_open) {  // an unread span: fold it into the pool
-      p->pool.push_back(p->factor_span.first);
-      p->pool.push_back(p->factor_span.second);
-    }
-    p->factor_span.first = prof_event(p);
-    p->factor_span.second = prof_event(p);
-    p->factor_open = true;
-    (void)hipEventRecord(p->factor_span.first, sA);
+    p->factor_spans.emplace_back(prof_event(p), prof_event(p));
+    (void)hipEventRecord(p->factor_spans.back().first, sA);
   }
   const int OB = f.OB;
   const int skip = getenv("PGF_SKIP") ? atoi(getenv("PGF_SKIP")) : 0;
@@ -873,7 +867,7 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
   if (N > 0)
     hipLaunchKernelGGL(k_inv_diag_blocks, dim3((N + 63) / 64), dim3(64), 0, sA, f.K, f.ldk, N,
                        f.Linv, f.LinvT);
-  if (p) (void)hipEventRecord(p->factor_span.second, sA);
+  if (p) (void)hipEventRecord(p->factor_spans.back().second, sA);
   e = hipMemcpyAsync(f.h_flags, f.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, sA);
   if (e != hipSuccess) return e;
   return hipGetLastError();
