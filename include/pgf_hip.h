@@ -42,6 +42,9 @@ extern "C" {
 #define PGF_HOST 0
 #define PGF_DEVICE 1
 
+/* pgf_create flags */
+#define PGF_CREATE_SPARSE 1u /* banded mode: CSR derivatives, no dense N x N storage */
+
 /* pgf_qp_step policy bits (NewtonMethod policies, newton.py:35-60, 63-89, 181-215) */
 #define PGF_STEP_RECOMPUTE_MASK 1u  /* Full, ActiveSet: mask from the current point  */
 #define PGF_STEP_REFACTOR 2u        /* Full: assemble + factor every step             */
@@ -116,6 +119,23 @@ int pgf_reduced_dims(pgf_handle h, int *n_inactive, int *n_reduced);
 /* copy the assembled (pre-factor) lower triangle of K to host, row-major N x N
  * (debug / parity; re-assembles, does not disturb the factor) */
 int pgf_get_kkt(pgf_handle h, double *K_out, int64_t ldk);
+
+/* ---- sparse (banded) mode: handle created with PGF_CREATE_SPARSE --------------------- */
+/* Fixed sparsity pattern of H (n x n CSR, both triangles) and J (m x n CSR) and the band
+ * plan computed on the host (pygradflow_amd/sparse.py): pos[i] = row of variable i /
+ * constraint n + r in the permuted banded KKT matrix, bw = half bandwidth, H/J slot =
+ * linear index into the band array for each stored entry (H: -1 for the mirrored upper
+ * duplicates), JT* = column-ordered copy of J's pattern (JTmap indexes Jval).  Replaces the
+ * scipy fancy-slicing / bmat assembly of symmetric_step_solver.py:27-39, 49-77 for sparse
+ * problems; active variables become identity rows instead of being sliced out. */
+int pgf_sparse_set_pattern(pgf_handle h, int bw, const int *pos, int nnzH, const int *Hptr,
+                           const int *Hrow, const int *Hcol, const int *Hslot, int nnzJ,
+                           const int *Jptr, const int *Jcol, const int *Jslot, const int *JTptr,
+                           const int *JTrow, const int *JTmap);
+/* values of H = lag_hess(x, y) and J = cons_jac(x) in pattern order (update_derivs) */
+int pgf_sparse_set_values(pgf_handle h, const double *Hval, const double *Jval);
+/* q and b of a linear-quadratic problem whose Q, A were given through the sparse pattern */
+int pgf_qp_set_vectors(pgf_handle h, const double *q, const double *b);
 
 /* ---- device-resident linear-quadratic mode (bench, batched mode) -------- */
 /* f = 1/2 x'Qx + q'x, c = Ax - b: H = Q and J = A stay in HBM; g and c are

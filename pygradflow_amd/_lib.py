@@ -23,6 +23,7 @@ LIB_PATH = os.path.join(_HERE, "libpgf_hip.so")
 PGF_OK, PGF_SINGULAR, PGF_INERTIA, PGF_INVALID, PGF_NOT_READY, PGF_HIP_ERROR = 0, 1, 2, 3, 4, 100
 PGF_HOST, PGF_DEVICE = 0, 1
 STEP_RECOMPUTE_MASK, STEP_REFACTOR, STEP_REFACTOR_ON_CHANGE = 1, 2, 4
+CREATE_SPARSE = 1
 
 _dp = C.POINTER(C.c_double)
 _u8p = C.POINTER(C.c_uint8)
@@ -47,6 +48,10 @@ SIGNATURES = {
     "pgf_linear_solve": (C.c_int, [_h, _dp, C.c_int, _dp]),
     "pgf_reduced_dims": (C.c_int, [_h, _ip, _ip]),
     "pgf_get_kkt": (C.c_int, [_h, _dp, C.c_int64]),
+    "pgf_sparse_set_pattern": (C.c_int, [_h, C.c_int, _ip, C.c_int, _ip, _ip, _ip, _ip, C.c_int, _ip, _ip, _ip,
+                                         _ip, _ip, _ip]),
+    "pgf_sparse_set_values": (C.c_int, [_h, _dp, _dp]),
+    "pgf_qp_set_vectors": (C.c_int, [_h, _dp, _dp]),
     "pgf_qp_set_problem": (C.c_int, [_h, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                                      C.c_void_p, C.c_int]),
     "pgf_qp_set_point": (C.c_int, [_h, _dp, _dp]),

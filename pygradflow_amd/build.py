@@ -16,6 +16,7 @@ ARCH = "gfx950"
 # active-set masks are compared bit-for-bit with numpy expressions.
 SOURCES = [
     ("pgf_kernels.hip", ["-ffp-contract=off"]),
+    ("pgf_sparse.hip", ["-ffp-contract=off"]),
     ("pgf_ldlt.hip", []),
     ("pgf_api.hip", ["-ffp-contract=off"]),
 ]

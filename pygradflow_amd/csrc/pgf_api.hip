@@ -9,6 +9,7 @@
 #include "../../include/pgf_hip.h"
 #include "pgf_internal.h"
 #include "pgf_kernels.h"
+#include "pgf_sparse.h"
 
 #define PGF_GEMVT_PARTS 32
 
@@ -39,6 +40,8 @@ struct pgf_solver {
   int *h_counts = nullptr;
   double *h_scal = nullptr;
   DenseLdlt fac;
+  SparseDev sp;
+  bool sparse = false;
   PgfProfile prof;
   bool step_pending = false;
 };
@@ -77,6 +80,17 @@ static hipError_t dalloc(T **p, size_t count) {
   return hipMalloc((void **)p, (count ? count : 1) * sizeof(T));
 }
 
+template <typename T>
+static int up_new(pgf_handle h, T **dst, const T *src, size_t count) {
+  if (*dst) {
+    (void)hipFree(*dst);
+    *dst = nullptr;
+  }
+  HIPCHK(h, dalloc(dst, count));
+  if (count) HIPCHK(h, hipMemcpyAsync(*dst, src, count * sizeof(T), hipMemcpyHostToDevice, h->stream));
+  return PGF_OK;
+}
+
 extern "C" {
 
 int pgf_version(void) { return 1; }
@@ -94,8 +108,8 @@ int pgf_device_count(int *count) {
 const char *pgf_last_error(pgf_handle h) { return h ? h->err.c_str() : k_no_handle; }
 
 int pgf_create(int n, int m, int device, unsigned flags, pgf_handle *out) {
-  (void)flags;
-  if (!out || n < 0 || m < 0 || (int64_t)n + m > 60000) return PGF_INVALID;
+  const bool sparse = (flags & PGF_CREATE_SPARSE) != 0;
+  if (!out || n < 0 || m < 0 || (!sparse && (int64_t)n + m > 60000)) return PGF_INVALID;
   pgf_handle h = new (std::nothrow) pgf_solver();
   if (!h) return PGF_INVALID;
   h->n = n;
@@ -128,7 +142,16 @@ int pgf_create(int n, int m, int device, unsigned flags, pgf_handle *out) {
     pgf_destroy(h);
     return PGF_HIP_ERROR + (int)e;
   }
-  if ((e = ldlt_alloc(h->fac, N, h->stream)) != hipSuccess) {
+  h->sparse = sparse;
+  if (sparse) {
+    // banded mode: no dense N x N storage; only the factor's flag words are shared
+    h->fac.stream = h->stream;
+    if ((e = hipMalloc((void **)&h->fac.flags, 4 * sizeof(int))) != hipSuccess ||
+        (e = hipHostMalloc((void **)&h->fac.h_flags, 4 * sizeof(int))) != hipSuccess) {
+      pgf_destroy(h);
+      return PGF_HIP_ERROR + (int)e;
+    }
+  } else if ((e = ldlt_alloc(h->fac, N, h->stream)) != hipSuccess) {
     pgf_destroy(h);
     return PGF_HIP_ERROR + (int)e;
   }
@@ -150,6 +173,13 @@ int pgf_destroy(pgf_handle h) {
     if (p) (void)hipFree(p);
   if (h->h_counts) (void)hipHostFree(h->h_counts);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
+  {
+    SparseDev &sp = h->sp;
+    void *sps[] = {sp.pos, sp.Hptr, sp.Hrow, sp.Hcol, sp.Hslot, sp.Jptr, sp.Jcol, sp.Jslot, sp.JTptr,
+                   sp.JTrow, sp.JTmap, sp.Hval, sp.Jval, sp.band, sp.brhs, sp.Hb0, sp.Jb0};
+    for (void *q : sps)
+      if (q) (void)hipFree(q);
+  }
   ldlt_free(h->fac);
   for (hipEvent_t e : h->prof.pool) (void)hipEventDestroy(e);
   for (auto &sp : h->prof.update_spans) {
@@ -300,6 +330,17 @@ int pgf_set_active_set(pgf_handle h, const uint8_t *mask) {
   (void)hipSetDevice(h->device);
   int rc;
   if ((rc = up(h, h->mask, mask, h->n))) return rc;
+  if (h->sparse) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int na = 0;
+    for (int i = 0; i < h->n; ++i) na += mask[i] ? 1 : 0;
+    h->nA = na;
+    h->nI = h->n - na;
+    h->N = h->nI + h->m;
+    h->mask_set = true;
+    invalidate_factor(h);
+    return PGF_OK;
+  }
   return refresh_index_sets(h);
 }
 
@@ -313,7 +354,8 @@ int pgf_reduced_dims(pgf_handle h, int *n_inactive, int *n_reduced) {
 
 static int check_ready(pgf_handle h) {
   if (!h->outer_set) return fail(h, PGF_NOT_READY, "pgf_set_outer first");
-  if (!h->derivs_set) return fail(h, PGF_NOT_READY, "pgf_set_derivs_* first");
+  if (h->sparse ? !h->sp.values_set : !h->derivs_set)
+    return fail(h, PGF_NOT_READY, "pgf_set_derivs_* / pgf_sparse_set_values first");
   if (!h->mask_set) return fail(h, PGF_NOT_READY, "pgf_set_active_set first");
   return PGF_OK;
 }
@@ -325,6 +367,16 @@ static void assemble(pgf_handle h, double *K, int64_t ldk) {
 
 // enqueue assemble + factor; with_rhs: carry h->rhs through the elimination in row N
 static int factor_async(pgf_handle h, bool with_rhs) {
+  if (h->sparse) {
+    // band assembly + banded LDL^T; the permuted rhs in sp.brhs is forward-substituted on
+    // the way (harmless when the caller only wants the factor)
+    sp_launch_assemble(h->stream, h->sp, h->n, h->m, h->mask, h->lamb, h->delta);
+    sp_launch_factor(h->stream, h->sp, h->n + h->m, h->fac.flags);
+    HIPCHK(h, hipMemcpyAsync(h->fac.h_flags, h->fac.flags, 4 * sizeof(int), hipMemcpyDeviceToHost,
+                             h->stream));
+    h->fac.factored = false;
+    return PGF_OK;
+  }
   assemble(h, h->fac.K, h->fac.ldk);
   if (with_rhs && h->N > 0)
     launch_copy(h->stream, h->fac.K + (int64_t)h->N * h->fac.ldk, h->rhs, h->N);
@@ -358,6 +410,23 @@ static int newton_core_async(pgf_handle h, bool *did_factor) {
   hipStream_t s = h->stream;
   launch_residual(s, h->n, h->m, h->lamb, h->dt, h->xhat, h->yhat, h->x, h->y, h->g, h->c, h->slb,
                   h->sub, h->mask, h->F, h->b0full);
+  if (h->sparse) {
+    const int Nf = h->n + h->m;
+    sp_launch_rhs(s, h->sp, h->n, h->m, h->mask, h->F, h->b0full, h->fact, h->sp.Hb0, h->sp.Jb0);
+    *did_factor = false;
+    if (!h->fac.factored) {
+      int rc;
+      if ((rc = factor_async(h, true))) return rc;
+      *did_factor = true;
+    } else {
+      sp_launch_fwdsolve(s, h->sp, Nf);
+    }
+    sp_launch_backsolve(s, h->sp, Nf);
+    sp_launch_step_update(s, h->sp, h->n, h->m, h->fact, h->rho, h->x, h->y, h->lb, h->ub, h->F,
+                          h->dx, h->dy, h->xn, h->yn, h->red);
+    launch_final_reduce(s, h->red, (h->n + h->m + 255) / 256, h->scal, 1);
+    return PGF_OK;
+  }
   launch_reduced_rhs(s, h->n, h->m, h->nI, h->nA, h->fact, h->F, h->idxI, h->H, h->ldh, h->J,
                      h->ldj, h->b0full, h->rhs);
   *did_factor = false;
@@ -436,6 +505,7 @@ int pgf_linear_solve(pgf_handle h, const double *rhs, int trans, double *sol) {
   int rc;
   if ((rc = check_ready(h))) return rc;
   if (h->N && (!rhs || !sol)) return fail(h, PGF_INVALID, "null argument");
+  if (h->sparse) return fail(h, PGF_NOT_READY, "pgf_linear_solve: dense mode only");
   (void)hipSetDevice(h->device);
   if (!h->fac.factored) {
     if ((rc = factor_async(h, false))) return rc;
@@ -453,6 +523,7 @@ int pgf_get_kkt(pgf_handle h, double *K_out, int64_t ldk_out) {
   int rc;
   if ((rc = check_ready(h))) return rc;
   const int N = h->N;
+  if (h->sparse) return fail(h, PGF_NOT_READY, "pgf_get_kkt: dense mode only");
   if (N == 0) return PGF_OK;
   if (!K_out || ldk_out < N) return fail(h, PGF_INVALID, "bad output matrix");
   (void)hipSetDevice(h->device);
@@ -466,6 +537,80 @@ int pgf_get_kkt(pgf_handle h, double *K_out, int64_t ldk_out) {
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   (void)hipFree(tmp);
   if (e != hipSuccess) return hip_fail(h, e, "pgf_get_kkt");
+  return PGF_OK;
+}
+
+// ---------------------------------------------------------------- sparse (banded) mode
+int pgf_sparse_set_pattern(pgf_handle h, int bw, const int *pos, int nnzH, const int *Hptr,
+                           const int *Hrow, const int *Hcol, const int *Hslot, int nnzJ,
+                           const int *Jptr, const int *Jcol, const int *Jslot, const int *JTptr,
+                           const int *JTrow, const int *JTmap) {
+  if (!h) return PGF_INVALID;
+  if (!h->sparse) return fail(h, PGF_NOT_READY, "handle was not created with PGF_CREATE_SPARSE");
+  if (bw < 0 || bw > 10) return fail(h, PGF_INVALID, "bandwidth must be 0..10 in this version");
+  if (nnzH < 0 || nnzJ < 0 || !pos || !Hptr || !Jptr || !JTptr)
+    return fail(h, PGF_INVALID, "null pattern");
+  (void)hipSetDevice(h->device);
+  SparseDev &sp = h->sp;
+  const int n = h->n, m = h->m, N = n + m;
+  sp.bw = bw;
+  sp.ldb = ((bw + 1) + 1) / 2 * 2;
+  sp.nnzH = nnzH;
+  sp.nnzJ = nnzJ;
+  int rc;
+  if ((rc = up_new(h, &sp.pos, pos, (size_t)N))) return rc;
+  if ((rc = up_new(h, &sp.Hptr, Hptr, (size_t)n + 1))) return rc;
+  if ((rc = up_new(h, &sp.Hrow, Hrow, (size_t)nnzH))) return rc;
+  if ((rc = up_new(h, &sp.Hcol, Hcol, (size_t)nnzH))) return rc;
+  if ((rc = up_new(h, &sp.Hslot, Hslot, (size_t)nnzH))) return rc;
+  if ((rc = up_new(h, &sp.Jptr, Jptr, (size_t)m + 1))) return rc;
+  if ((rc = up_new(h, &sp.Jcol, Jcol, (size_t)nnzJ))) return rc;
+  if ((rc = up_new(h, &sp.Jslot, Jslot, (size_t)nnzJ))) return rc;
+  if ((rc = up_new(h, &sp.JTptr, JTptr, (size_t)n + 1))) return rc;
+  if ((rc = up_new(h, &sp.JTrow, JTrow, (size_t)nnzJ))) return rc;
+  if ((rc = up_new(h, &sp.JTmap, JTmap, (size_t)nnzJ))) return rc;
+  for (double **q : {&sp.Hval, &sp.Jval, &sp.band, &sp.brhs, &sp.Hb0, &sp.Jb0})
+    if (*q) {
+      (void)hipFree(*q);
+      *q = nullptr;
+    }
+  HIPCHK(h, dalloc(&sp.Hval, (size_t)nnzH));
+  HIPCHK(h, dalloc(&sp.Jval, (size_t)nnzJ));
+  HIPCHK(h, dalloc(&sp.band, (size_t)(N + 1) * sp.ldb));
+  HIPCHK(h, dalloc(&sp.brhs, (size_t)N + 1));
+  HIPCHK(h, dalloc(&sp.Hb0, (size_t)n + 1));
+  HIPCHK(h, dalloc(&sp.Jb0, (size_t)m + 1));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  sp.active = true;
+  sp.values_set = false;
+  invalidate_factor(h);
+  return PGF_OK;
+}
+
+int pgf_sparse_set_values(pgf_handle h, const double *Hval, const double *Jval) {
+  if (!h) return PGF_INVALID;
+  if (!h->sparse || !h->sp.active) return fail(h, PGF_NOT_READY, "pgf_sparse_set_pattern first");
+  if ((h->sp.nnzH && !Hval) || (h->sp.nnzJ && !Jval)) return fail(h, PGF_INVALID, "null values");
+  (void)hipSetDevice(h->device);
+  int rc;
+  if ((rc = up(h, h->sp.Hval, Hval, (size_t)h->sp.nnzH * sizeof(double)))) return rc;
+  if ((rc = up(h, h->sp.Jval, Jval, (size_t)h->sp.nnzJ * sizeof(double)))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->sp.values_set = true;
+  h->derivs_set = true;
+  invalidate_factor(h);
+  return PGF_OK;
+}
+
+int pgf_qp_set_vectors(pgf_handle h, const double *q, const double *b) {
+  if (!h) return PGF_INVALID;
+  if ((h->n && !q) || (h->m && !b)) return fail(h, PGF_INVALID, "null argument");
+  (void)hipSetDevice(h->device);
+  int rc;
+  if ((rc = up(h, h->q, q, h->n * sizeof(double)))) return rc;
+  if ((rc = up(h, h->b, b, h->m * sizeof(double)))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->qp_mode = true;
   return PGF_OK;
 }
 
@@ -527,6 +672,15 @@ int pgf_qp_get_mask(pgf_handle h, uint8_t *mask) {
 static void qp_eval(pgf_handle h) {
   if (h->eval_fresh) return;
   hipStream_t s = h->stream;
+  if (h->sparse) {
+    const SparseDev &sp = h->sp;
+    sp_launch_spmv(s, h->m, sp.Jptr, sp.Jcol, sp.Jval, h->x, h->b, -1.0, h->c);
+    launch_mult_vec(s, h->m, h->rho, h->c, h->y, h->w);
+    sp_launch_spmvT(s, h->n, sp.JTptr, sp.JTrow, sp.JTmap, sp.Jval, h->w, h->q, h->tmpn);
+    sp_launch_spmv(s, h->n, sp.Hptr, sp.Hcol, sp.Hval, h->x, h->tmpn, 1.0, h->g);
+    h->eval_fresh = true;
+    return;
+  }
   launch_gemv_rows(s, h->m, h->n, h->J, h->ldj, h->x, h->b, -1.0, h->c);
   launch_mult_vec(s, h->m, h->rho, h->c, h->y, h->w);
   launch_gemvT(s, h->m, h->n, h->J, h->ldj, h->w, h->q, h->partial, PGF_GEMVT_PARTS, h->tmpn);
@@ -561,6 +715,11 @@ static int qp_refresh_mask(pgf_handle h, double tau, bool force, int *changed_ou
   if (changed_out) *changed_out = changed;
   if (changed) {
     launch_copy_u8(s, h->mask, h->mask_new, h->n);
+    if (h->sparse) {  // full-size banded system: no index sets to rebuild
+      h->mask_set = true;
+      invalidate_factor(h);
+      return PGF_OK;
+    }
     return refresh_index_sets(h);
   }
   return PGF_OK;

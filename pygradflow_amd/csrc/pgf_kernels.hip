@@ -456,3 +456,7 @@ void launch_unscaled_res_norm(hipStream_t s, int n, int m, double dt, const doub
                        c, lb, ub, red);
   hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(256), 0, s, red, nb, out, 1);
 }
+
+void launch_final_reduce(hipStream_t s, const double *red, int cnt, double *out, int take_sqrt) {
+  hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(256), 0, s, red, cnt, out, take_sqrt);
+}

@@ -1,0 +1,36 @@
+// Sparse (banded) mode of the step solver: device data and launch wrappers (pgf_sparse.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct SparseDev {
+  bool active = false;
+  int bw = 0, ldb = 0;
+  int nnzH = 0, nnzJ = 0;
+  int *pos = nullptr;                       // permuted position of variable i / constraint n + r
+  int *Hptr = nullptr, *Hrow = nullptr, *Hcol = nullptr, *Hslot = nullptr;
+  int *Jptr = nullptr, *Jcol = nullptr, *Jslot = nullptr;
+  int *JTptr = nullptr, *JTrow = nullptr, *JTmap = nullptr;
+  double *Hval = nullptr, *Jval = nullptr;
+  double *band = nullptr;                   // (N + 1) x ldb
+  double *brhs = nullptr;                   // permuted right-hand side / solution
+  double *Hb0 = nullptr, *Jb0 = nullptr;
+  bool values_set = false;
+};
+
+void sp_launch_spmv(hipStream_t s, int rows, const int *ptr, const int *col, const double *val,
+                    const double *x, const double *add, double sgn, double *y);
+void sp_launch_spmvT(hipStream_t s, int cols, const int *tptr, const int *trow, const int *tmap,
+                     const double *val, const double *w, const double *base, double *out);
+void sp_launch_assemble(hipStream_t s, const SparseDev &sp, int n, int m, const uint8_t *mask,
+                        double lamb, double delta);
+void sp_launch_rhs(hipStream_t s, const SparseDev &sp, int n, int m, const uint8_t *mask,
+                   const double *F, const double *b0full, double fact, double *Hb0, double *Jb0);
+void sp_launch_factor(hipStream_t s, const SparseDev &sp, int N, int *flags);
+void sp_launch_fwdsolve(hipStream_t s, const SparseDev &sp, int N);
+void sp_launch_backsolve(hipStream_t s, const SparseDev &sp, int N);
+void sp_launch_step_update(hipStream_t s, const SparseDev &sp, int n, int m, double fact,
+                           double rho, const double *x, const double *y, const double *lb,
+                           const double *ub, const double *F, double *dx, double *dy, double *xn,
+                           double *yn, double *red);

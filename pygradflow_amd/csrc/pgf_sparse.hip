@@ -1,0 +1,355 @@
+// Sparse (banded) variant of the Newton/KKT step: CSR Hessian / Jacobian resident in HBM,
+// KKT matrix assembled into a symmetric band (after a host-computed bandwidth-reducing
+// permutation of the FIXED full pattern), banded LDL^T and banded triangular solves.
+//
+// The reduced system of the reference (symmetric_step_solver.py:49-94) drops the active
+// rows / columns; here the system keeps its full size n + m and an active variable a
+// becomes an identity row / column with right-hand side b0[a].  The two systems have the
+// same solution on the inactive set, s[a] = b0[a] is what the reference scatters into
+// dx[A] anyway (symmetric_step_solver.py:115-121), the added unit pivots are positive so
+// the inertia count is unchanged, and -- the point -- the sparsity pattern, permutation
+// and band layout never change while the mask churns.
+//
+// Band layout: row i of the permuted matrix stores K[i][i - d] at band[i * ldb + d],
+// d = 0 .. bw (lower band, row-major); ldb = bw + 1 rounded up to even.
+//
+// Compiled with -ffp-contract=off like pgf_kernels.hip (explicit fma() only).
+#include "pgf_sparse.h"
+
+#define ACTIVE_EPS 1e-8
+
+// ---------------------------------------------------------------- CSR products
+// y[r] = sum_k val[k] * x[col[k]]  (+ sgn * add[r]);  rows are short: one lane per row
+__global__ void k_csr_spmv(int rows, const int *__restrict__ ptr, const int *__restrict__ col,
+                           const double *__restrict__ val, const double *__restrict__ x,
+                           const double *__restrict__ add, double sgn, double *__restrict__ y) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  double acc = 0.0;
+  for (int k = ptr[r]; k < ptr[r + 1]; ++k) acc = fma(val[k], x[col[k]], acc);
+  y[r] = add ? acc + sgn * add[r] : acc;
+}
+
+// out[j] = base[j] + sum_k val[map[k]] * w[row[k]] over the entries of column j
+// (transposed product through the column-ordered copy of the pattern: no atomics)
+__global__ void k_csc_spmvT(int cols, const int *__restrict__ tptr, const int *__restrict__ trow,
+                            const int *__restrict__ tmap, const double *__restrict__ val,
+                            const double *__restrict__ w, const double *__restrict__ base,
+                            double *__restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cols) return;
+  double acc = 0.0;
+  for (int k = tptr[j]; k < tptr[j + 1]; ++k) acc = fma(val[tmap[k]], w[trow[k]], acc);
+  out[j] = base[j] + acc;
+}
+
+// ---------------------------------------------------------------- band assembly
+// diagonal: lamb (inactive variable), 1 (active variable), -delta (constraint)
+__global__ void k_band_set_diag(int n, int m, const int *__restrict__ pos,
+                                const uint8_t *__restrict__ mask, double lamb, double delta,
+                                double *__restrict__ band, int ldb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n + m) return;
+  double v;
+  if (i < n)
+    v = mask[i] ? 1.0 : lamb;
+  else
+    v = -delta;
+  band[(int64_t)pos[i] * ldb] = v;
+}
+
+// H entries (lower part in permuted order; slot < 0 marks the mirrored duplicates)
+__global__ void k_band_scatter_H(int nnz, const int *__restrict__ row, const int *__restrict__ col,
+                                 const double *__restrict__ val, const int *__restrict__ slot,
+                                 const uint8_t *__restrict__ mask, double *__restrict__ band) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nnz) return;
+  const int s = slot[k];
+  if (s < 0) return;
+  if (mask[row[k]] || mask[col[k]]) return;
+  band[s] += val[k];  // slots are unique per entry; the diagonal was set before this launch
+}
+
+__global__ void k_band_scatter_J(int nnz, const int *__restrict__ col,
+                                 const double *__restrict__ val, const int *__restrict__ slot,
+                                 const uint8_t *__restrict__ mask, double *__restrict__ band) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nnz) return;
+  if (mask[col[k]]) return;
+  band[slot[k]] = val[k];
+}
+
+// full-size right-hand side in permuted order:
+//   variable i inactive: F_i - (H b0)_i     active: b0_i = dt F_i
+//   constraint r       : fact F_{n+r} - (J b0)_r
+__global__ void k_band_rhs(int n, int m, const uint8_t *__restrict__ mask,
+                           const double *__restrict__ F, const double *__restrict__ b0full,
+                           const double *__restrict__ Hb0, const double *__restrict__ Jb0,
+                           double fact, const int *__restrict__ pos, double *__restrict__ brhs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n + m) return;
+  double v;
+  if (i < n)
+    v = mask[i] ? b0full[i] : F[i] - Hb0[i];
+  else
+    v = fact * F[i] - Jb0[i - n];
+  brhs[pos[i]] = v;
+}
+
+// ---------------------------------------------------------------- banded LDL^T + forward solve
+__device__ __forceinline__ double recip2(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-d, r, 1.0);
+  return fma(r, e, r);
+}
+
+#define BAND_LDS_DOUBLES 15360  // 120 KB panel of band rows + right-hand side
+
+// One wavefront walks the band.  Panels of P rows are staged in LDS (coalesced loads),
+// columns are eliminated one after the other inside the panel (lane <-> pair (r, k) of
+// the (bw+1)^2 / 2 window update), consecutive panels overlap by bw rows through global
+// memory.  The right-hand side rides along (forward substitution for free).  The chain
+// pivot -> reciprocal -> update -> next pivot is inherently serial: this kernel is
+// latency-bound by design; the planned successor partitions the band into independent
+// segments with a small dense Schur complement.
+__global__ __launch_bounds__(64) void k_band_factor(double *__restrict__ band, int ldb, int bw,
+                                                    double *__restrict__ rhs, int N,
+                                                    int *__restrict__ flags) {
+  __shared__ double sm[BAND_LDS_DOUBLES];
+  const int lane = threadIdx.x;
+  const int P = BAND_LDS_DOUBLES / (ldb + 1);
+  double *Bp = sm;            // [P][ldb]
+  double *rp = sm + P * ldb;  // [P]
+  // lane -> pair (r, k), 1 <= k <= r <= bw
+  const int npairs = bw * (bw + 1) / 2;
+  int r = 0, k = 0;
+  if (lane < npairs) {
+    int t = lane;
+    r = 1;
+    while (t >= r) {
+      t -= r;
+      ++r;
+    }
+    k = t + 1;
+  }
+  const bool act = lane < npairs;
+  int neg = 0, bad = 0;
+  const int stepP = P - bw;
+  for (int s0 = 0; s0 < N; s0 += stepP) {
+    const int rows = min(P, N - s0);
+    // stage rows [s0, s0 + rows) (+ zero padding up to P)
+    for (int idx = lane; idx < P * ldb; idx += 64) {
+      const int rr = idx / ldb;
+      Bp[idx] = (rr < rows) ? band[(int64_t)s0 * ldb + idx] : 0.0;
+    }
+    for (int idx = lane; idx < P; idx += 64) rp[idx] = (idx < rows) ? rhs[s0 + idx] : 0.0;
+    __syncthreads();
+    // columns whose whole window lies in the panel (all remaining ones in the last panel)
+    const bool last = (s0 + P >= N);
+    const int ncols = last ? rows : stepP;
+    for (int j = 0; j < ncols; ++j) {
+      const double d = Bp[j * ldb];
+      const bool isbad = (d == 0.0) || !(fabs(d) <= 1.79e308);
+      const double di = isbad ? 0.0 : recip2(d);
+      bad |= isbad ? 1 : 0;
+      neg += (d < 0.0) ? 1 : 0;
+      if (act && j + r < P) {
+        const double cr = Bp[(j + r) * ldb + r];
+        const double ck = Bp[(j + k) * ldb + k];
+        const double l = cr * di;
+        double t = Bp[(j + r) * ldb + (r - k)];
+        t = fma(-l, ck, t);
+        double rr = 0.0;
+        if (k == r) rr = fma(-l, rp[j], rp[j + r]);
+        Bp[(j + r) * ldb + (r - k)] = t;
+        if (k == r) rp[j + r] = rr;
+        if (k == 1) Bp[(j + r) * ldb + r] = l;  // L entry (column read by all lanes above)
+      }
+    }
+    __syncthreads();
+    for (int idx = lane; idx < rows * ldb; idx += 64) band[(int64_t)s0 * ldb + idx] = Bp[idx];
+    for (int idx = lane; idx < rows; idx += 64) rhs[s0 + idx] = rp[idx];
+    __threadfence();  // the next panel re-reads the bw overlapping rows from memory
+    __syncthreads();
+    if (last) break;
+  }
+  if (lane == 0) {
+    if (bad) atomicOr(&flags[0], 1);
+    if (neg) atomicAdd(&flags[1], neg);
+  }
+}
+
+// y <- L^-1 z with the stored factor (back-solve steps that reuse a factorisation):
+// mirror image of k_band_backsolve, walking forward.
+__global__ __launch_bounds__(64) void k_band_fwdsolve(const double *__restrict__ band, int ldb,
+                                                      int bw, double *__restrict__ z, int N) {
+  __shared__ double sm[BAND_LDS_DOUBLES];
+  const int lane = threadIdx.x;
+  const int P = BAND_LDS_DOUBLES / (ldb + 1);
+  double *Bp = sm;
+  double *zp = sm + P * ldb;
+  const int rr = lane + 1;
+  const int stepP = P - bw;
+  for (int s0 = 0; s0 < N; s0 += stepP) {
+    const int rows = min(P, N - s0);
+    for (int idx = lane; idx < rows * ldb; idx += 64) Bp[idx] = band[(int64_t)s0 * ldb + idx];
+    for (int idx = lane; idx < rows; idx += 64) zp[idx] = z[s0 + idx];
+    __syncthreads();
+    const bool last = (s0 + P >= N);
+    const int ncols = last ? rows : stepP;
+    for (int j = 0; j < ncols; ++j) {
+      const double yj = zp[j];
+      if (rr <= bw && j + rr < rows) zp[j + rr] = fma(-Bp[(j + rr) * ldb + rr], yj, zp[j + rr]);
+    }
+    __syncthreads();
+    for (int idx = lane; idx < rows; idx += 64) z[s0 + idx] = zp[idx];
+    __threadfence();
+    __syncthreads();
+    if (last) break;
+  }
+}
+
+// z <- D^-1 z
+__global__ void k_band_scale(double *__restrict__ z, const double *__restrict__ band, int ldb,
+                             int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) z[i] = z[i] / band[(int64_t)i * ldb];
+}
+
+// x <- L^-T z, sequential from the last row (right-looking: once x_i is final it is folded
+// into the bw entries above it, lane <-> distance r).  Panels of P rows in LDS, walked from
+// the end; a panel finalises and propagates its rows [bw, P) and hands its top bw rows
+// (complete, but not yet propagated upwards) to the next panel through global memory.
+__global__ __launch_bounds__(64) void k_band_backsolve(const double *__restrict__ band, int ldb,
+                                                       int bw, double *__restrict__ z, int N) {
+  __shared__ double sm[BAND_LDS_DOUBLES];
+  const int lane = threadIdx.x;
+  const int P = BAND_LDS_DOUBLES / (ldb + 1);
+  double *Bp = sm;
+  double *zp = sm + P * ldb;
+  const int rr = lane + 1;
+  int e0 = N;
+  while (e0 > 0) {
+    const int s0 = max(0, e0 - P);
+    const int rows = e0 - s0;
+    for (int idx = lane; idx < rows * ldb; idx += 64) Bp[idx] = band[(int64_t)s0 * ldb + idx];
+    for (int idx = lane; idx < rows; idx += 64) zp[idx] = z[s0 + idx];
+    __syncthreads();
+    const int lo = (s0 == 0) ? 0 : bw;
+    for (int i = rows - 1; i >= lo; --i) {
+      const double xi = zp[i];
+      if (rr <= bw && i - rr >= 0) zp[i - rr] = fma(-Bp[i * ldb + rr], xi, zp[i - rr]);
+    }
+    __syncthreads();
+    for (int idx = lane; idx < rows; idx += 64) z[s0 + idx] = zp[idx];
+    __threadfence();
+    __syncthreads();
+    if (s0 == 0) break;
+    e0 = s0 + bw;
+  }
+}
+
+// ---------------------------------------------------------------- step update (a9, a15, a16)
+__global__ __launch_bounds__(256) void k_band_step_update(
+    int n, int m, const int *__restrict__ pos, const double *__restrict__ sol, double fact,
+    double rho, const double *__restrict__ x, const double *__restrict__ y,
+    const double *__restrict__ lb, const double *__restrict__ ub, const double *__restrict__ F,
+    double *__restrict__ dx, double *__restrict__ dy, double *__restrict__ xn,
+    double *__restrict__ yn, double *__restrict__ red) {
+  __shared__ double part[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double sq = 0.0;
+  if (i < n) {
+    double d = sol[pos[i]];
+    const double xi = x[i];
+    double v = xi - d;
+    const double lo = lb[i], hi = ub[i];
+    if (v < lo) {
+      v = lo;
+      d = xi - lo;
+    }
+    if (v > hi) {
+      v = hi;
+      d = xi - hi;
+    }
+    dx[i] = d;
+    xn[i] = v;
+    sq = d * d;
+  } else if (i < n + m) {
+    const int r = i - n;
+    const double t = rho * F[i];
+    const double d = fact * (sol[pos[i]] - t);
+    dy[r] = d;
+    yn[r] = y[r] - d;
+    sq = d * d;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sq;
+  __syncthreads();
+  if (threadIdx.x == 0) red[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// ---------------------------------------------------------------- launch wrappers
+static inline dim3 g1(int n, int b = 256) { return dim3((n + b - 1) / b); }
+
+void sp_launch_spmv(hipStream_t s, int rows, const int *ptr, const int *col, const double *val,
+                    const double *x, const double *add, double sgn, double *y) {
+  if (rows) hipLaunchKernelGGL(k_csr_spmv, g1(rows), dim3(256), 0, s, rows, ptr, col, val, x, add, sgn, y);
+}
+
+void sp_launch_spmvT(hipStream_t s, int cols, const int *tptr, const int *trow, const int *tmap,
+                     const double *val, const double *w, const double *base, double *out) {
+  if (cols)
+    hipLaunchKernelGGL(k_csc_spmvT, g1(cols), dim3(256), 0, s, cols, tptr, trow, tmap, val, w, base, out);
+}
+
+void sp_launch_assemble(hipStream_t s, const SparseDev &sp, int n, int m, const uint8_t *mask,
+                        double lamb, double delta) {
+  const int N = n + m;
+  (void)hipMemsetAsync(sp.band, 0, (size_t)(N + 1) * sp.ldb * sizeof(double), s);
+  hipLaunchKernelGGL(k_band_set_diag, g1(N), dim3(256), 0, s, n, m, sp.pos, mask, lamb, delta,
+                     sp.band, sp.ldb);
+  if (sp.nnzH)
+    hipLaunchKernelGGL(k_band_scatter_H, g1(sp.nnzH), dim3(256), 0, s, sp.nnzH, sp.Hrow, sp.Hcol,
+                       sp.Hval, sp.Hslot, mask, sp.band);
+  if (sp.nnzJ)
+    hipLaunchKernelGGL(k_band_scatter_J, g1(sp.nnzJ), dim3(256), 0, s, sp.nnzJ, sp.Jcol, sp.Jval,
+                       sp.Jslot, mask, sp.band);
+}
+
+void sp_launch_rhs(hipStream_t s, const SparseDev &sp, int n, int m, const uint8_t *mask,
+                   const double *F, const double *b0full, double fact, double *Hb0, double *Jb0) {
+  sp_launch_spmv(s, n, sp.Hptr, sp.Hcol, sp.Hval, b0full, nullptr, 0.0, Hb0);
+  sp_launch_spmv(s, m, sp.Jptr, sp.Jcol, sp.Jval, b0full, nullptr, 0.0, Jb0);
+  hipLaunchKernelGGL(k_band_rhs, g1(n + m), dim3(256), 0, s, n, m, mask, F, b0full, Hb0, Jb0, fact,
+                     sp.pos, sp.brhs);
+}
+
+void sp_launch_factor(hipStream_t s, const SparseDev &sp, int N, int *flags) {
+  (void)hipMemsetAsync(flags, 0, 4 * sizeof(int), s);
+  hipLaunchKernelGGL(k_band_factor, dim3(1), dim3(64), 0, s, sp.band, sp.ldb, sp.bw, sp.brhs, N, flags);
+}
+
+void sp_launch_fwdsolve(hipStream_t s, const SparseDev &sp, int N) {
+  if (N == 0) return;
+  hipLaunchKernelGGL(k_band_fwdsolve, dim3(1), dim3(64), 0, s, sp.band, sp.ldb, sp.bw, sp.brhs, N);
+}
+
+void sp_launch_backsolve(hipStream_t s, const SparseDev &sp, int N) {
+  if (N == 0) return;
+  hipLaunchKernelGGL(k_band_scale, g1(N), dim3(256), 0, s, sp.brhs, sp.band, sp.ldb, N);
+  hipLaunchKernelGGL(k_band_backsolve, dim3(1), dim3(64), 0, s, sp.band, sp.ldb, sp.bw, sp.brhs, N);
+}
+
+void sp_launch_step_update(hipStream_t s, const SparseDev &sp, int n, int m, double fact,
+                           double rho, const double *x, const double *y, const double *lb,
+                           const double *ub, const double *F, double *dx, double *dy, double *xn,
+                           double *yn, double *red) {
+  const int nb = (n + m + 255) / 256;
+  if (nb)
+    hipLaunchKernelGGL(k_band_step_update, dim3(nb), dim3(256), 0, s, n, m, sp.pos, sp.brhs, fact,
+                       rho, x, y, lb, ub, F, dx, dy, xn, yn, red);
+}

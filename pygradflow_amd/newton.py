@@ -22,7 +22,8 @@ import numpy as np
 from . import _lib
 from .errors import LinearSolverError, StepSolverError
 from .params import enum_name
-from .step_solver import POOL, HipStepSolver
+from .sparse import MAX_BANDWIDTH, BandPlan
+from .step_solver import DENSE_LIMIT, POOL, HipStepSolver
 
 
 # --------------------------------------------------------------------------- policies
@@ -152,7 +153,9 @@ class DeviceNewton:
         self.n, self.m = problem.num_vars, problem.num_cons
         self.dt, self.rho = float(dt), float(rho)
         self.tau = math.nan if tau is None else float(tau)
-        self._hd = POOL.acquire(self.n, self.m, device)
+        self.sparse = (not problem.is_dense) and (
+            bool(getattr(problem, "pgf_force_band", False)) or self.n + self.m > DENSE_LIMIT)
+        self._hd = POOL.acquire(self.n, self.m, device, sparse=self.sparse)
         h = self._hd.h
         lib = self._lib
         lb, ub = _lib.as_f64(problem.var_lb), _lib.as_f64(problem.var_ub)
@@ -161,7 +164,20 @@ class DeviceNewton:
         if key is None:
             key = object()
             problem._pgf_token = key
-        if self._hd.derivs_key is not key or not getattr(self._hd, "qp_loaded", False):
+        if self.sparse and (self._hd.derivs_key is not key or not getattr(self._hd, "qp_loaded", False)):
+            plan = BandPlan(problem.hess_sparse(), problem.jac_sparse(), self.n, self.m)
+            if not plan.supported:
+                raise NotImplementedError(f"banded path: half-bandwidth {plan.bw} > {MAX_BANDWIDTH}")
+            plan.upload(lib, h)
+            hv, jv = plan.values(problem.hess_sparse(), problem.jac_sparse())
+            _lib.check(lib.pgf_sparse_set_values(h, _lib.dptr(hv), _lib.dptr(jv)), h,
+                       "pgf_sparse_set_values")
+            q, b = _lib.as_f64(problem.q), _lib.as_f64(problem.b)
+            _lib.check(lib.pgf_qp_set_vectors(h, _lib.dptr(q), _lib.dptr(b)), h, "pgf_qp_set_vectors")
+            self._hd.plan = plan
+            self._hd.derivs_key = key
+            self._hd.qp_loaded = True
+        elif self._hd.derivs_key is not key or not getattr(self._hd, "qp_loaded", False):
             Q = np.ascontiguousarray(problem.hess_dense(), dtype=np.float64)
             A = np.ascontiguousarray(problem.jac_dense(), dtype=np.float64).reshape(self.m, self.n)
             q, b = _lib.as_f64(problem.q), _lib.as_f64(problem.b)

@@ -25,6 +25,9 @@ import scipy.sparse as sps
 from . import _lib
 from .errors import LinearSolverError, StepSolverError
 from .linear_solver import HipLinearSolver
+from .sparse import BandPlan, MAX_BANDWIDTH
+
+DENSE_LIMIT = 20000  # n + m above which sparse derivatives take the banded path
 
 
 # --------------------------------------------------------------------------- handles
@@ -35,18 +38,19 @@ class _HandlePool:
     def __init__(self):
         self._free = {}
 
-    def acquire(self, n, m, device):
-        key = (n, m, device)
+    def acquire(self, n, m, device, sparse=False):
+        key = (n, m, device, bool(sparse))
         lst = self._free.get(key)
         if lst:
             return lst.pop()
         lib = _lib.load()
         h = C.c_void_p()
-        _lib.check(lib.pgf_create(n, m, device, 0, C.byref(h)), None, "pgf_create")
-        return _Handle(h, n, m, device)
+        flags = _lib.CREATE_SPARSE if sparse else 0
+        _lib.check(lib.pgf_create(n, m, device, flags, C.byref(h)), None, "pgf_create")
+        return _Handle(h, n, m, device, bool(sparse))
 
     def release(self, handle):
-        self._free.setdefault((handle.n, handle.m, handle.device), []).append(handle)
+        self._free.setdefault((handle.n, handle.m, handle.device, handle.sparse), []).append(handle)
 
     def clear(self):
         lib = _lib.load()
@@ -57,9 +61,10 @@ class _HandlePool:
 
 
 class _Handle:
-    def __init__(self, h, n, m, device):
-        self.h, self.n, self.m, self.device = h, n, m, device
+    def __init__(self, h, n, m, device, sparse=False):
+        self.h, self.n, self.m, self.device, self.sparse = h, n, m, device, sparse
         self.derivs_key = None  # identity of the matrices currently resident in HBM
+        self.plan = None        # BandPlan of a sparse handle
         self.keepalive = None
 
 
@@ -188,7 +193,9 @@ class HipStepSolver:
         self._derivs_dirty = True
         self._mask_dirty = True
         self._outer_sent = False
-        self._hd = POOL.acquire(self.n, self.m, device)
+        # sparse (banded) mode: problems too large for a dense KKT matrix, or on request
+        self.sparse = bool(getattr(problem, "pgf_force_band", False)) or (self.n + self.m > DENSE_LIMIT)
+        self._hd = POOL.acquire(self.n, self.m, device, sparse=self.sparse)
         self._func = HipStepFunc(self)
         self.last_n_neg = None
 
@@ -272,7 +279,10 @@ class HipStepSolver:
                         self.problem._pgf_token = key
                     except Exception:
                         key = None
-            if key is None or hd.derivs_key is not key:
+            if self.sparse and (key is None or hd.derivs_key is not key):
+                self._push_sparse_derivs()
+                hd.derivs_key = key
+            elif key is None or hd.derivs_key is not key:
                 H = _dense_f64(self._hess, (self.n, self.n))
                 J = _dense_f64(self._jac, (self.m, self.n))
                 rc = self._lib.pgf_set_derivs_dense(
@@ -286,13 +296,41 @@ class HipStepSolver:
             _lib.check(self._lib.pgf_set_active_set(hd.h, _lib.u8ptr(mask)), hd.h, "pgf_set_active_set")
             self._mask_dirty = False
 
+    def _push_sparse_derivs(self):
+        hd = self._hd
+        hess = sps.csr_matrix(self._hess)
+        jac = sps.csr_matrix(self._jac) if self.m else sps.csr_matrix((0, self.n))
+        for attempt in (0, 1):
+            if hd.plan is None:
+                plan = BandPlan(hess, jac, self.n, self.m)
+                if not plan.supported:
+                    raise NotImplementedError(
+                        f"banded path supports half-bandwidth <= {MAX_BANDWIDTH} after RCM "
+                        f"(got {plan.bw}); this problem needs the general sparse path")
+                plan.upload(self._lib, hd.h)
+                hd.plan = plan
+            try:
+                hv, jv = hd.plan.values(hess, jac)
+                break
+            except ValueError:
+                if attempt:
+                    raise
+                hd.plan = None  # pattern changed: re-plan once
+        _lib.check(self._lib.pgf_sparse_set_values(hd.h, _lib.dptr(hv), _lib.dptr(jv)), hd.h,
+                   "pgf_sparse_set_values")
+
     def reduced_dims(self):
+        if self.sparse:
+            ni = int(self.n - np.count_nonzero(self.active_set))
+            return ni, ni + self.m
         a, b = C.c_int(0), C.c_int(0)
         _lib.check(self._lib.pgf_reduced_dims(self._hd.h, C.byref(a), C.byref(b)), self._hd.h)
         return a.value, b.value
 
     def kkt_matrix(self):
         """Assembled reduced KKT matrix (lower triangle) -- debug / parity only."""
+        if self.sparse:
+            raise NotImplementedError("kkt_matrix: dense mode only")
         self._push_state()
         _, N = self.reduced_dims()
         K = np.zeros((N, N), dtype=np.float64)
@@ -336,6 +374,8 @@ class _DeviceFactorView:
 
     def solve(self, rhs, trans=False, initial_sol=None):
         o = self._o
+        if o.sparse:
+            raise NotImplementedError("solve against the banded factor is not exposed yet")
         rhs = _lib.as_f64(rhs)
         sol = np.empty_like(rhs)
         rc = o._lib.pgf_linear_solve(o._hd.h, _lib.dptr(rhs), int(bool(trans)), _lib.dptr(sol))

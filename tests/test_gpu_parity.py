@@ -255,3 +255,87 @@ def test_batched_single_rank(pgf):
         assert abs(dn.residual_norm() - norms[i]) <= 1e-12 * max(1.0, norms[i])
         dn.close()
     bd.close()
+
+
+# ------------------------------------------------------------------ sparse (banded) path
+def _as_sparse_lq(problem):
+    from pygradflow_amd import problems
+
+    sp = problems.LinearQuadraticProblem(
+        sps.csr_matrix(problem.hess_dense()), problem.q,
+        sps.csr_matrix(problem.jac_dense().reshape(problem.num_cons, problem.num_vars)),
+        problem.b, problem.var_lb, problem.var_ub)
+    sp.pgf_force_band = True
+    return sp
+
+
+@pytest.mark.parametrize("name", ["ocp_m40", "box_qp_n256", "boxed_qp49"])
+def test_banded_path_golden(pgf, name):
+    """Sparse banded mode (CSR derivatives, band assembly, banded LDL^T) against the reference
+    trajectories: plugin path (HipStepSolver) and device-resident driver."""
+    case = G.load_case(name)
+    problem = _as_sparse_lq(G.rebuild_problem(case))
+    dt, rho, tau = float(case["dt"]), float(case["rho"]), G.case_tau(case)
+    for pol in case["policies"]:
+        params = pgf.Params(newton_type=str(pol), step_solver=pgf.HipStepSolver)
+        orig = pgf.Iterate(problem, params, case["x0"], case["y0"])
+        gen = pgf.newton_steps(problem, params, orig, dt, rho, tau)
+        dn = pgf.DeviceNewton(problem, str(pol), case["x0"], case["y0"], dt, rho, tau)
+        assert dn.sparse
+        for k in range(int(case["steps"])):
+            pre = f"{pol}/{k}/"
+            step = next(gen)
+            assert np.array_equal(step.active_set, case[pre + "mask"]), (pol, k)
+            assert G.rel_err(step.iterate.x, case[pre + "xn"]) <= TOL, (pol, k)
+            assert G.rel_err(step.iterate.y, case[pre + "yn"]) <= TOL, (pol, k)
+            diff, n_neg = dn.step()
+            x, y = dn.point()
+            assert np.array_equal(dn.mask(), case[pre + "mask"]), (pol, k)
+            assert G.rel_err(x, case[pre + "xn"]) <= TOL, (pol, k)
+            assert G.rel_err(y, case[pre + "yn"]) <= TOL, (pol, k)
+            assert abs(diff - float(case[pre + "diff"])) <= TOL * max(1.0, diff)
+            # active variables are kept as unit pivots: the negative count is unchanged
+            assert n_neg == int(case[pre + "n_neg"])
+        dn.close()
+
+
+@pytest.mark.parametrize("m", [3000, 50000])
+def test_banded_ocp_against_oracle(pgf, m):
+    """BASELINE config 3 (sparse optimal-control NLP; m = 50000 is the full size
+    n = 100000, N = 150000) against the CPU oracle, 3 Full steps + Simplified back-solves."""
+    from pygradflow_amd import problems
+
+    prob = problems.sparse_ocp(m, seed=0)
+    n = 2 * m
+    x0, y0 = np.zeros(n), np.zeros(m)
+    for pol, steps in (("Full", 3), ("Simplified", 2)):
+        recs = O.NewtonOracle(prob, pol, x0, y0, 1.0, 1.0).run(x0, y0, steps)
+        dn = pgf.DeviceNewton(prob, pol, x0, y0, 1.0, 1.0)
+        assert dn.sparse or m < 5000
+        for k, rec in enumerate(recs):
+            diff, n_neg = dn.step()
+            x, y = dn.point()
+            assert not dn.mask().any()
+            assert G.rel_err(x, rec["xn"]) <= TOL, (pol, k)
+            assert G.rel_err(y, rec["yn"]) <= TOL, (pol, k)
+            assert n_neg == m
+        dn.close()
+
+
+def test_banded_box_qp_mask_churn(pgf):
+    """Config 5 as given (tridiagonal H, n = 16384, m = 0) through the banded path."""
+    from pygradflow_amd import problems
+
+    n = 16384
+    prob = problems.box_qp(n, seed=0)
+    prob.pgf_force_band = True
+    x0, y0 = np.zeros(n), np.zeros(0)
+    recs = O.NewtonOracle(prob, "Full", x0, y0, 1.0, 1.0).run(x0, y0, 6)
+    dn = pgf.DeviceNewton(prob, "Full", x0, y0, 1.0, 1.0)
+    assert dn.sparse
+    for k, rec in enumerate(recs):
+        dn.step()
+        x, _ = dn.point()
+        assert np.array_equal(dn.mask(), rec["mask"]), k
+        assert G.rel_err(x, rec["xn"]) <= TOL, k
+    dn.close()
