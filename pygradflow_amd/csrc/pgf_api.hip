@@ -371,7 +371,26 @@ static int factor_async(pgf_handle h, bool with_rhs) {
     // band assembly + banded LDL^T; the permuted rhs in sp.brhs is forward-substituted on
     // the way (harmless when the caller only wants the factor)
     sp_launch_assemble(h->stream, h->sp, h->n, h->m, h->mask, h->lamb, h->delta);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->prof.enabled) {  // time the dominant (sequential, HBM/latency-bound) kernel
+      for (hipEvent_t *e : {&e0, &e1}) {
+        if (!h->prof.pool.empty()) {
+          *e = h->prof.pool.back();
+          h->prof.pool.pop_back();
+        } else {
+          (void)hipEventCreate(e);
+        }
+      }
+      (void)hipEventRecord(e0, h->stream);
+    }
     sp_launch_factor(h->stream, h->sp, h->n + h->m, h->fac.flags);
+    if (e0) {
+      (void)hipEventRecord(e1, h->stream);
+      h->prof.update_spans.emplace_back(e0, e1);
+      // "flops" slot carries the algorithmic BYTES of the launch here: the band and the
+      // right-hand side are read once and written once
+      h->prof.update_flops.push_back(2.0 * (double)(h->n + h->m) * (h->sp.ldb + 1) * 8.0);
+    }
     HIPCHK(h, hipMemcpyAsync(h->fac.h_flags, h->fac.flags, 4 * sizeof(int), hipMemcpyDeviceToHost,
                              h->stream));
     h->fac.factored = false;
