@@ -210,11 +210,12 @@ def main():
         dn.step()
         xg, yg = dn.point()
         r0 = recs[0]
-        den = max(1.0, np.max(np.abs(r0["xn"])))
+        def _rel(a, b):
+            return float(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b)))) if b.size else 0.0
+
         parity = dict(
             mask_hamming=int(np.count_nonzero(dn.mask() != r0["mask"])),
-            iterate_rel_err=float(max(np.max(np.abs(xg - r0["xn"])) / den,
-                                      np.max(np.abs(yg - r0["yn"])) / max(1.0, np.max(np.abs(r0["yn"]))))),
+            iterate_rel_err=max(_rel(xg, r0["xn"]), _rel(yg, r0["yn"])),
         )
         cpu = dict(value=rate, unit="Newton steps/s", cores=1, kind="port",
                    sample=f"{csteps} Full Newton step(s) of {args.workload} from x0=y0=0 "
