@@ -176,7 +176,8 @@ int pgf_destroy(pgf_handle h) {
   {
     SparseDev &sp = h->sp;
     void *sps[] = {sp.pos, sp.Hptr, sp.Hrow, sp.Hcol, sp.Hslot, sp.Jptr, sp.Jcol, sp.Jslot, sp.JTptr,
-                   sp.JTrow, sp.JTmap, sp.Hval, sp.Jval, sp.band, sp.brhs, sp.Hb0, sp.Jb0};
+                   sp.JTrow, sp.JTmap, sp.Hval, sp.Jval, sp.band, sp.brhs, sp.Hb0, sp.Jb0,
+                   sp.bD, sp.bL, sp.bU, sp.bDinv, sp.bF, sp.bX};
     for (void *q : sps)
       if (q) (void)hipFree(q);
   }
@@ -371,25 +372,12 @@ static int factor_async(pgf_handle h, bool with_rhs) {
     // band assembly + banded LDL^T; the permuted rhs in sp.brhs is forward-substituted on
     // the way (harmless when the caller only wants the factor)
     sp_launch_assemble(h->stream, h->sp, h->n, h->m, h->mask, h->lamb, h->delta);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->prof.enabled) {  // time the dominant (sequential, HBM/latency-bound) kernel
-      for (hipEvent_t *e : {&e0, &e1}) {
-        if (!h->prof.pool.empty()) {
-          *e = h->prof.pool.back();
-          h->prof.pool.pop_back();
-        } else {
-          (void)hipEventCreate(e);
-        }
-      }
-      (void)hipEventRecord(e0, h->stream);
-    }
-    sp_launch_factor(h->stream, h->sp, h->n + h->m, h->fac.flags);
-    if (e0) {
-      (void)hipEventRecord(e1, h->stream);
-      h->prof.update_spans.emplace_back(e0, e1);
-      // "flops" slot carries the algorithmic BYTES of the launch here: the band and the
-      // right-hand side are read once and written once
-      h->prof.update_flops.push_back(2.0 * (double)(h->n + h->m) * (h->sp.ldb + 1) * 8.0);
+    if (h->sp.bw <= 8 && !getenv("PGF_BAND_SEQ")) {
+      // cyclic-reduction mode keeps the assembled band intact; run one reduction (on
+      // whatever right-hand side is there) only to obtain the pivot flags / inertia
+      sp_launch_bcr_solve(h->stream, h->sp, h->n + h->m, h->fac.flags);
+    } else {
+      sp_launch_factor(h->stream, h->sp, h->n + h->m, h->fac.flags);
     }
     HIPCHK(h, hipMemcpyAsync(h->fac.h_flags, h->fac.flags, 4 * sizeof(int), hipMemcpyDeviceToHost,
                              h->stream));
@@ -433,14 +421,44 @@ static int newton_core_async(pgf_handle h, bool *did_factor) {
     const int Nf = h->n + h->m;
     sp_launch_rhs(s, h->sp, h->n, h->m, h->mask, h->F, h->b0full, h->fact, h->sp.Hb0, h->sp.Jb0);
     *did_factor = false;
-    if (!h->fac.factored) {
-      int rc;
-      if ((rc = factor_async(h, true))) return rc;
-      *did_factor = true;
+    if (h->sp.bw <= 8 && !getenv("PGF_BAND_SEQ")) {
+      // block cyclic reduction: assemble (only when the mask / derivatives changed) and
+      // solve in log2(N/8) parallel levels; the band itself is left untouched, so a
+      // back-solve step just runs the reduction again on the same band (~1 ms)
+      if (!h->fac.factored) sp_launch_assemble(s, h->sp, h->n, h->m, h->mask, h->lamb, h->delta);
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (h->prof.enabled) {
+        for (hipEvent_t *e : {&e0, &e1}) {
+          if (!h->prof.pool.empty()) {
+            *e = h->prof.pool.back();
+            h->prof.pool.pop_back();
+          } else {
+            (void)hipEventCreate(e);
+          }
+        }
+        (void)hipEventRecord(e0, s);
+      }
+      sp_launch_bcr_solve(s, h->sp, Nf, h->fac.flags);
+      if (e0) {
+        (void)hipEventRecord(e1, s);
+        h->prof.update_spans.emplace_back(e0, e1);
+        // algorithmic bytes of one cyclic-reduction solve: every block (D, L, U, inv D:
+        // 4 x 512 B, rhs + solution 128 B) is written once and read about twice
+        h->prof.update_flops.push_back(3.0 * (double)((Nf + 7) / 8) * (4 * 512 + 128));
+      }
+      HIPCHK(h, hipMemcpyAsync(h->fac.h_flags, h->fac.flags, 4 * sizeof(int),
+                               hipMemcpyDeviceToHost, s));
+      *did_factor = true;  // flags need checking at the sync
     } else {
-      sp_launch_fwdsolve(s, h->sp, Nf);
+      if (!h->fac.factored) {
+        int rc;
+        if ((rc = factor_async(h, true))) return rc;
+        *did_factor = true;
+      } else {
+        sp_launch_fwdsolve(s, h->sp, Nf);
+      }
+      sp_launch_backsolve(s, h->sp, Nf);
     }
-    sp_launch_backsolve(s, h->sp, Nf);
     sp_launch_step_update(s, h->sp, h->n, h->m, h->fact, h->rho, h->x, h->y, h->lb, h->ub, h->F,
                           h->dx, h->dy, h->xn, h->yn, h->red);
     launch_final_reduce(s, h->red, (h->n + h->m + 255) / 256, h->scal, 1);
@@ -588,7 +606,8 @@ int pgf_sparse_set_pattern(pgf_handle h, int bw, const int *pos, int nnzH, const
   if ((rc = up_new(h, &sp.JTptr, JTptr, (size_t)n + 1))) return rc;
   if ((rc = up_new(h, &sp.JTrow, JTrow, (size_t)nnzJ))) return rc;
   if ((rc = up_new(h, &sp.JTmap, JTmap, (size_t)nnzJ))) return rc;
-  for (double **q : {&sp.Hval, &sp.Jval, &sp.band, &sp.brhs, &sp.Hb0, &sp.Jb0})
+  for (double **q : {&sp.Hval, &sp.Jval, &sp.band, &sp.brhs, &sp.Hb0, &sp.Jb0, &sp.bD, &sp.bL, &sp.bU,
+                     &sp.bDinv, &sp.bF, &sp.bX})
     if (*q) {
       (void)hipFree(*q);
       *q = nullptr;
@@ -599,6 +618,15 @@ int pgf_sparse_set_pattern(pgf_handle h, int bw, const int *pos, int nnzH, const
   HIPCHK(h, dalloc(&sp.brhs, (size_t)N + 1));
   HIPCHK(h, dalloc(&sp.Hb0, (size_t)n + 1));
   HIPCHK(h, dalloc(&sp.Jb0, (size_t)m + 1));
+  {
+    const size_t nbk = (size_t)(N + 7) / 8 + 1;
+    HIPCHK(h, dalloc(&sp.bD, nbk * 64));
+    HIPCHK(h, dalloc(&sp.bL, nbk * 64));
+    HIPCHK(h, dalloc(&sp.bU, nbk * 64));
+    HIPCHK(h, dalloc(&sp.bDinv, nbk * 64));
+    HIPCHK(h, dalloc(&sp.bF, nbk * 8));
+    HIPCHK(h, dalloc(&sp.bX, nbk * 8));
+  }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   sp.active = true;
   sp.values_set = false;

@@ -16,6 +16,8 @@ struct SparseDev {
   double *band = nullptr;                   // (N + 1) x ldb
   double *brhs = nullptr;                   // permuted right-hand side / solution
   double *Hb0 = nullptr, *Jb0 = nullptr;
+  // block cyclic reduction work arrays: (N/8) blocks of 8 x 8 (D, L, U, inv D), rhs, solution
+  double *bD = nullptr, *bL = nullptr, *bU = nullptr, *bDinv = nullptr, *bF = nullptr, *bX = nullptr;
   bool values_set = false;
 };
 
@@ -28,6 +30,7 @@ void sp_launch_assemble(hipStream_t s, const SparseDev &sp, int n, int m, const 
 void sp_launch_rhs(hipStream_t s, const SparseDev &sp, int n, int m, const uint8_t *mask,
                    const double *F, const double *b0full, double fact, double *Hb0, double *Jb0);
 void sp_launch_factor(hipStream_t s, const SparseDev &sp, int N, int *flags);
+void sp_launch_bcr_solve(hipStream_t s, const SparseDev &sp, int N, int *flags);
 void sp_launch_fwdsolve(hipStream_t s, const SparseDev &sp, int N);
 void sp_launch_backsolve(hipStream_t s, const SparseDev &sp, int N);
 void sp_launch_step_update(hipStream_t s, const SparseDev &sp, int n, int m, double fact,

@@ -353,3 +353,231 @@ void sp_launch_step_update(hipStream_t s, const SparseDev &sp, int n, int m, dou
     hipLaunchKernelGGL(k_band_step_update, dim3(nb), dim3(256), 0, s, n, m, sp.pos, sp.brhs, fact,
                        rho, x, y, lb, ub, F, dx, dy, xn, yn, red);
 }
+
+// ================================================================= block cyclic reduction
+// The permuted KKT matrix has half-bandwidth bw <= 8, i.e. it is block tridiagonal with
+// 8 x 8 blocks: D_i (diagonal), L_i (coupling to the left neighbour), U_i = L_{i+1}^T.
+// Cyclic reduction eliminates every other block row per level (all of them in parallel):
+//   kept block i, eliminated neighbours i-s, i+s:
+//     alpha = L_i inv(D_{i-s}),  gamma = U_i inv(D_{i+s})
+//     D_i -= alpha U_{i-s} + gamma L_{i+s};  f_i -= alpha f_{i-s} + gamma f_{i+s}
+//     L_i <- -alpha L_{i-s}  (now couples to i-2s);  U_i <- -gamma U_{i+s}
+// log2(N/8) levels instead of N sequential pivots; back-substitution walks the levels in
+// reverse.  Every principal block and Schur complement of a symmetric quasi-definite matrix
+// is again quasi-definite, so the 8 x 8 pivots D_i are invertible without pivoting, and by
+// Haynsworth's inertia additivity the number of negative eigenvalues of K is the sum of the
+// negative pivots met while inverting the D_i.  One wavefront per block, lane <-> (row, col).
+#define BCR_B 8
+
+// block extraction from the band (+ identity padding of the last block)
+__global__ __launch_bounds__(64) void k_bcr_extract(const double *__restrict__ band, int ldb, int bw,
+                                                    const double *__restrict__ rhs, int N, int nb,
+                                                    double *__restrict__ D, double *__restrict__ L,
+                                                    double *__restrict__ U, double *__restrict__ F) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const int r = lane >> 3, c = lane & 7;
+  const int gr = i * 8 + r, gc = i * 8 + c;
+  // diagonal block, symmetric fill
+  double d = (r == c) ? 1.0 : 0.0;
+  if (gr < N && gc < N) {
+    const int hi = max(gr, gc), lo = min(gr, gc);
+    d = (hi - lo <= bw) ? band[(int64_t)hi * ldb + (hi - lo)] : 0.0;
+  }
+  D[(int64_t)i * 64 + lane] = d;
+  // L_i[r][c] = K[8i + r][8(i-1) + c]
+  double l = 0.0;
+  if (i > 0 && gr < N) {
+    const int cc = (i - 1) * 8 + c;
+    const int dist = gr - cc;
+    if (dist <= bw) l = band[(int64_t)gr * ldb + dist];
+  }
+  L[(int64_t)i * 64 + lane] = l;
+  // U_i[r][c] = K[8i + r][8(i+1) + c] = K[8(i+1) + c][8i + r]
+  double u = 0.0;
+  if (i + 1 < nb && gr < N) {
+    const int rr = (i + 1) * 8 + c;
+    const int dist = rr - gr;
+    if (rr < N && dist <= bw) u = band[(int64_t)rr * ldb + dist];
+  }
+  U[(int64_t)i * 64 + lane] = u;
+  if (lane < 8) F[(int64_t)i * 8 + lane] = (i * 8 + lane < N) ? rhs[i * 8 + lane] : 0.0;
+}
+
+// in-place Gauss-Jordan inverse of the 8 x 8 block in LDS (one wavefront, lane = (r, c));
+// returns the number of negative pivots, sets *bad on a zero / non-finite pivot
+__device__ __forceinline__ int gj_inverse8(double *M, int lane, int *bad) {
+  const int r = lane >> 3, c = lane & 7;
+  int neg = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const double p = M[k * 8 + k];
+    const bool isbad = (p == 0.0) || !(fabs(p) <= 1.79e308);
+    *bad |= isbad ? 1 : 0;
+    neg += (p < 0.0) ? 1 : 0;
+    const double d = isbad ? 0.0 : 1.0 / p;
+    const double mrk = M[r * 8 + k], mkc = M[k * 8 + c], mrc = M[lane];
+    double v;
+    if (r == k && c == k)
+      v = d;
+    else if (r == k)
+      v = mkc * d;
+    else if (c == k)
+      v = -mrk * d;
+    else
+      v = fma(-mrk * d, mkc, mrc);
+    M[lane] = v;  // all lanes have read before any lane writes (one wavefront, lockstep)
+  }
+  return neg;
+}
+
+// invert the blocks eliminated at this level: i = s, 3s, 5s, ... (i mod 2s == s)
+__global__ __launch_bounds__(64) void k_bcr_invert(const double *__restrict__ D,
+                                                   double *__restrict__ Dinv, int nb, int s,
+                                                   int first, int stride, int *__restrict__ flags) {
+  __shared__ double M[64];
+  const int i = first + blockIdx.x * stride, lane = threadIdx.x;
+  if (i >= nb) return;
+  M[lane] = D[(int64_t)i * 64 + lane];
+  int bad = 0;
+  const int neg = gj_inverse8(M, lane, &bad);
+  Dinv[(int64_t)i * 64 + lane] = M[lane];
+  if (lane == 0) {
+    if (bad) atomicOr(&flags[0], 1);
+    if (neg) atomicAdd(&flags[1], neg);
+  }
+  (void)s;
+}
+
+// 8 x 8 product helper: out[r][c] = sum_k A[r][k] B[k][c], operands in LDS
+__device__ __forceinline__ double mm8(const double *A, const double *B, int r, int c) {
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc = fma(A[r * 8 + k], B[k * 8 + c], acc);
+  return acc;
+}
+
+// reduce the kept blocks of this level: i = 0, 2s, 4s, ...
+__global__ __launch_bounds__(64) void k_bcr_reduce(double *__restrict__ D, double *__restrict__ L,
+                                                   double *__restrict__ U, double *__restrict__ F,
+                                                   const double *__restrict__ Dinv, int nb, int s) {
+  __shared__ double A[64], B[64], T[64], fs[8];
+  const int i = blockIdx.x * 2 * s, lane = threadIdx.x;
+  if (i >= nb) return;
+  const int r = lane >> 3, c = lane & 7;
+  double dv = D[(int64_t)i * 64 + lane];
+  double fv = (lane < 8) ? F[(int64_t)i * 8 + lane] : 0.0;
+  double lnew = 0.0, unew = 0.0;
+  const int le = i - s, ri = i + s;
+  if (le >= 0) {
+    A[lane] = L[(int64_t)i * 64 + lane];
+    B[lane] = Dinv[(int64_t)le * 64 + lane];
+    const double al = mm8(A, B, r, c);  // alpha = L_i inv(D_left)
+    T[lane] = al;
+    B[lane] = U[(int64_t)le * 64 + lane];
+    if (lane < 8) fs[lane] = F[(int64_t)le * 8 + lane];
+    dv -= mm8(T, B, r, c);              // D_i -= alpha U_left
+    if (lane < 8) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc = fma(T[lane * 8 + k], fs[k], acc);
+      fv -= acc;                        // f_i -= alpha f_left
+    }
+    B[lane] = L[(int64_t)le * 64 + lane];
+    lnew = -mm8(T, B, r, c);            // couples i to i - 2s
+  }
+  if (ri < nb) {
+    A[lane] = U[(int64_t)i * 64 + lane];
+    B[lane] = Dinv[(int64_t)ri * 64 + lane];
+    const double ga = mm8(A, B, r, c);  // gamma = U_i inv(D_right)
+    T[lane] = ga;
+    B[lane] = L[(int64_t)ri * 64 + lane];
+    if (lane < 8) fs[lane] = F[(int64_t)ri * 8 + lane];
+    dv -= mm8(T, B, r, c);              // D_i -= gamma L_right
+    if (lane < 8) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc = fma(T[lane * 8 + k], fs[k], acc);
+      fv -= acc;
+    }
+    B[lane] = U[(int64_t)ri * 64 + lane];
+    unew = -mm8(T, B, r, c);            // couples i to i + 2s
+  }
+  D[(int64_t)i * 64 + lane] = dv;
+  L[(int64_t)i * 64 + lane] = lnew;
+  U[(int64_t)i * 64 + lane] = unew;
+  if (lane < 8) F[(int64_t)i * 8 + lane] = fv;
+}
+
+// back-substitution of the blocks eliminated at this level (i mod 2s == s), and of the
+// single remaining block when s == 0 (first = 0, stride irrelevant):
+//   x_i = inv(D_i) (f_i - L_i x_{i-s} - U_i x_{i+s})
+__global__ __launch_bounds__(64) void k_bcr_back(const double *__restrict__ Dinv,
+                                                 const double *__restrict__ L,
+                                                 const double *__restrict__ U,
+                                                 const double *__restrict__ F,
+                                                 double *__restrict__ X, int nb, int s, int first,
+                                                 int stride) {
+  __shared__ double t[8], xl[8], xr[8];
+  const int i = first + blockIdx.x * stride, lane = threadIdx.x;
+  if (i >= nb) return;
+  const int le = i - s, ri = i + s;
+  const bool hl = (s > 0) && le >= 0, hr = (s > 0) && ri < nb;
+  if (lane < 8) {
+    xl[lane] = hl ? X[(int64_t)le * 8 + lane] : 0.0;
+    xr[lane] = hr ? X[(int64_t)ri * 8 + lane] : 0.0;
+  }
+  if (lane < 8) {
+    double acc = F[(int64_t)i * 8 + lane];
+    if (hl)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc = fma(-L[(int64_t)i * 64 + lane * 8 + k], xl[k], acc);
+    if (hr)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc = fma(-U[(int64_t)i * 64 + lane * 8 + k], xr[k], acc);
+    t[lane] = acc;
+  }
+  if (lane < 8) {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc = fma(Dinv[(int64_t)i * 64 + lane * 8 + k], t[k], acc);
+    X[(int64_t)i * 8 + lane] = acc;
+  }
+}
+
+__global__ void k_bcr_scatter(const double *__restrict__ X, double *__restrict__ out, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) out[i] = X[i];
+}
+
+// Solve the banded system in sp.band / sp.brhs by block cyclic reduction; the solution
+// replaces sp.brhs.  flags[0] zero pivot, flags[1] negative pivots.
+void sp_launch_bcr_solve(hipStream_t s, const SparseDev &sp, int N, int *flags) {
+  (void)hipMemsetAsync(flags, 0, 4 * sizeof(int), s);
+  if (N == 0) return;
+  const int nb = (N + 7) / 8;
+  hipLaunchKernelGGL(k_bcr_extract, dim3(nb), dim3(64), 0, s, sp.band, sp.ldb, sp.bw, sp.brhs, N, nb,
+                     sp.bD, sp.bL, sp.bU, sp.bF);
+  int top = 1;
+  for (int st = 1; st < nb; st *= 2) {
+    const int ne = (nb - st + 2 * st - 1) / (2 * st);  // eliminated: st, 3st, ...
+    if (ne > 0)
+      hipLaunchKernelGGL(k_bcr_invert, dim3(ne), dim3(64), 0, s, sp.bD, sp.bDinv, nb, st, st,
+                         2 * st, flags);
+    const int nk = (nb + 2 * st - 1) / (2 * st);       // kept: 0, 2st, ...
+    hipLaunchKernelGGL(k_bcr_reduce, dim3(nk), dim3(64), 0, s, sp.bD, sp.bL, sp.bU, sp.bF, sp.bDinv,
+                       nb, st);
+    top = st;
+  }
+  // the last remaining block (index 0)
+  hipLaunchKernelGGL(k_bcr_invert, dim3(1), dim3(64), 0, s, sp.bD, sp.bDinv, nb, 0, 0, 1, flags);
+  hipLaunchKernelGGL(k_bcr_back, dim3(1), dim3(64), 0, s, sp.bDinv, sp.bL, sp.bU, sp.bF, sp.bX, nb, 0,
+                     0, 1);
+  if (nb > 1)
+    for (int st = top; st >= 1; st /= 2) {
+      const int ne = (nb - st + 2 * st - 1) / (2 * st);
+      if (ne > 0)
+        hipLaunchKernelGGL(k_bcr_back, dim3(ne), dim3(64), 0, s, sp.bDinv, sp.bL, sp.bU, sp.bF, sp.bX,
+                           nb, st, st, 2 * st);
+    }
+  hipLaunchKernelGGL(k_bcr_scatter, g1(N), dim3(256), 0, s, sp.bX, sp.brhs, N);
+}
