@@ -33,6 +33,24 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
+// Loads of data another kernel may have written while a second queue was resident (the
+// look-ahead schedule): system-scope relaxed atomic loads (global_load ... sc0 sc1) bypass
+// the per-XCD L2, which is not coherent with the other XCDs' L2s.
+__device__ __forceinline__ double ld_f64(const double *p, int coh) {
+  if (coh) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return *p;
+}
+__device__ __forceinline__ double2_t ld_f64x2(const double *p, int coh) {
+  double2_t v;
+  if (coh) {
+    v.x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    v.y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else {
+    v = *reinterpret_cast<const double2_t *>(p);
+  }
+  return v;
+}
+
 // 1 / d to within an ulp or two: v_rcp_f64 seed + two Newton steps (5 dependent ops
 // instead of the ~12 of an IEEE-correct division; the pivots only enter through
 // products, which the 1e-10 iterate tolerance covers with 5 digits to spare)
@@ -81,6 +99,7 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
   const int l15 = lane & 15, l4 = lane >> 4;
   const int nb = min(NB, N - c0);
   const int rbase = c0 + nb + wg * 64;  // first own row (global)
+  const int coh = (skip >> 3) & 1;      // bit 3 of `skip`: system-scope loads (look-ahead)
   if (tid == 0) s_bad = 0;
 
   // ---- load: diag block (identity outside the valid lower triangle) + own rows.
@@ -96,8 +115,8 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
       if (row < 64) {
         if (row < nb) {
           const double *src = K + (int64_t)(c0 + row) * ldk + c0 + c2;
-          if (c2 + 1 <= row) t = *reinterpret_cast<const double2_t *>(src);
-          else if (c2 <= row) t.x = src[0];
+          if (c2 + 1 <= row) t = ld_f64x2(src, coh);
+          else if (c2 <= row) t.x = ld_f64(src, coh);
         } else {  // identity padding keeps the elimination well defined
           if (c2 == row) t.x = 1.0;
           if (c2 + 1 == row) t.y = 1.0;
@@ -106,8 +125,8 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
         const int r = rbase + row - 64;
         if (r < nrows) {
           const double *src = K + (int64_t)r * ldk + c0 + c2;
-          if (c2 + 1 < nb) t = *reinterpret_cast<const double2_t *>(src);
-          else if (c2 < nb) t.x = src[0];
+          if (c2 + 1 < nb) t = ld_f64x2(src, coh);
+          else if (c2 < nb) t.x = ld_f64(src, coh);
         }
       }
       v[q] = t;
@@ -274,7 +293,9 @@ template <int BM, int BN, int BK, int WR = 2, int WC = 2, int DB = 0>
 __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, const int j0,
                                             double *__restrict__ K, int64_t ldk,
                                             const double *__restrict__ W, int64_t ldw, int N,
-                                            int nrows, int colEnd, int kc0, int KB) {
+                                            int nrows, int colEnd, int kc0, int KBc) {
+  const int KB = KBc & 0xFFFFF;        // K-depth
+  const int coh = (KBc >> 20) & 1;     // bit 20: system-scope loads (look-ahead schedule)
   constexpr int NT = 64 * WR * WC;           // threads per workgroup
   constexpr int WM = BM / WR, WN = BN / WC;  // rows / columns per wavefront
   constexpr int TM = WM / 16, TN = WN / 16;  // MFMA tiles per wavefront
@@ -301,7 +322,7 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, c
       for (int r = 0; r < 4; ++r) {
         const int i = i0 + wr * WM + mi * 16 + l4 + 4 * r;
         double v = 0.0;
-        if (i < nrows && j < colEnd && j <= i) v = K[(int64_t)i * ldk + j];
+        if (i < nrows && j < colEnd && j <= i) v = ld_f64(K + (int64_t)i * ldk + j, coh);
         acc[mi][nj][r] = v;
       }
     }
@@ -317,7 +338,7 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, c
       const int row = p / PPR, kofs = (p % PPR) * 2;
       const int gi = i0 + row;
       double2_t va = (double2_t){0.0, 0.0};
-      if (gi < nrows) va = *reinterpret_cast<const double2_t *>(W + (int64_t)gi * ldw + kk + kofs);
+      if (gi < nrows) va = ld_f64x2(W + (int64_t)gi * ldw + kk + kofs, coh);
       pa[q] = va;
     }
 #pragma unroll
@@ -327,7 +348,7 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, c
       const int gj = j0 + row;
       double2_t vb = (double2_t){0.0, 0.0};
       if (gj < colEnd)
-        vb = *reinterpret_cast<const double2_t *>(K + (int64_t)gj * ldk + kc0 + kk + kofs);
+        vb = ld_f64x2(K + (int64_t)gj * ldk + kc0 + kk + kofs, coh);
       pb[q] = vb;
     }
   };
@@ -732,7 +753,7 @@ static hipEvent_t prof_event(PgfProfile *p) {
 // bracketed by profiling events.
 static void launch_update(DenseLdlt &f, hipStream_t s, const double *Wp, int64_t ldw, int N,
                           int nrows, int row0, int col0, int colEnd, int kc0, int KB,
-                          PgfProfile *p) {
+                          PgfProfile *p, int coh = 0) {
   if (row0 >= nrows || col0 >= colEnd) return;
   // 64 x 64 tiles (96 VGPRs, 5 wavefronts per SIMD) beat 128 x 128 tiles (249 VGPRs, 2 per
   // SIMD) at every region size measured (tools/bench_update.py): the kernel lives on
@@ -747,7 +768,7 @@ static void launch_update(DenseLdlt &f, hipStream_t s, const double *Wp, int64_t
     (void)hipEventRecord(e0, s);
   }
   hipLaunchKernelGGL((k_ldlt_update<64, 64, 16>), dim3(tc, tr), dim3(256), 0, s, f.K, f.ldk, Wp,
-                     ldw, N, nrows, row0, col0, colEnd, kc0, KB);
+                     ldw, N, nrows, row0, col0, colEnd, kc0, KB | (coh << 20));
   if (p) {
     (void)hipEventRecord(e1, s);
     p->update_spans.emplace_back(e0, e1);
@@ -783,7 +804,30 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
     (void)hipEventRecord(p->factor_spans.back().first, sA);
   }
   const int OB = f.OB;
-  const int skip = getenv("PGF_SKIP") ? atoi(getenv("PGF_SKIP")) : 0;
+  // PGF_LOOKAHEAD=1: bulk update of outer block i on a second stream, overlapped with the
+  // panels of block i + 1; PGF_COHERENT (default 1 with look-ahead): stream-A kernels and
+  // (bit 1) the bulk kernel load with system scope, see ld_f64
+  const bool la = getenv("PGF_LOOKAHEAD") != nullptr;
+  const int cohm = la ? (getenv("PGF_COHERENT") ? atoi(getenv("PGF_COHERENT")) : 1) : 0;
+  const int cohA = cohm & 1, cohB = (cohm >> 1) & 1;
+  hipStream_t sB = la ? f.stream2 : f.stream;
+  int evi = 0;
+  auto next_event = [&]() -> hipEvent_t {
+    if ((size_t)evi >= f.ev_ring.size()) {
+      hipEvent_t ev;
+      (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+      f.ev_ring.push_back(ev);
+    }
+    return f.ev_ring[evi++];
+  };
+  hipEvent_t ev_b_done = nullptr;
+  bool b_pending = false;
+  if (la) {  // stream B must not start before everything already queued on A
+    hipEvent_t ev0 = next_event();
+    (void)hipEventRecord(ev0, sA);
+    (void)hipStreamWaitEvent(sB, ev0, 0);
+  }
+  const int skip = (getenv("PGF_SKIP") ? atoi(getenv("PGF_SKIP")) : 0) | (cohA << 3);
   // filler tiles in the panel launches: correct, but not yet a win (the panel's 87 KB of
   // LDS leaves one filler workgroup per CU, and the tile kernel needs several per SIMD)
   const bool fuse = getenv("PGF_FUSE") != nullptr;
@@ -841,15 +885,24 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
       }
       const int c1 = c0 + PGF_NB;
       if (c1 < obEnd)  // inner update: the rest of this outer block's columns, K = 64
-        launch_update(f, sA, Wb + (c0 - ob0), OB, N, nrows, c1, c1, obEnd, c0, PGF_NB, p);
+        launch_update(f, sA, Wb + (c0 - ob0), OB, N, nrows, c1, c1, obEnd, c0, PGF_NB, p, cohA);
     }
     pend.active = false;
     if (obEnd < N) {
       const int KB = obEnd - ob0;  // == OB here (only the last outer block may be short)
       const int nextEnd = std::min(obEnd + OB, N);
-      launch_update(f, sA, Wb, OB, N, nrows, obEnd, obEnd, nextEnd, ob0, KB, p);
+      if (la && b_pending) (void)hipStreamWaitEvent(sA, ev_b_done, 0);  // RMW order
+      launch_update(f, sA, Wb, OB, N, nrows, obEnd, obEnd, nextEnd, ob0, KB, p, cohA);
       if (nextEnd < N) {
-        if (fuse) {
+        if (la) {
+          hipEvent_t ev_a = next_event();
+          (void)hipEventRecord(ev_a, sA);
+          (void)hipStreamWaitEvent(sB, ev_a, 0);
+          launch_update(f, sB, Wb, OB, N, nrows, nextEnd, nextEnd, N, ob0, KB, p, cohB);
+          ev_b_done = next_event();
+          (void)hipEventRecord(ev_b_done, sB);
+          b_pending = true;
+        } else if (fuse) {
           const int TR = (nrows - nextEnd + UPD_BM - 1) / UPD_BM;
           pend.active = true;
           pend.Wp = Wb;
@@ -864,6 +917,7 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
       }
     }
   }
+  if (la && b_pending) (void)hipStreamWaitEvent(sA, ev_b_done, 0);
   if (N > 0)
     hipLaunchKernelGGL(k_inv_diag_blocks, dim3((N + 63) / 64), dim3(64), 0, sA, f.K, f.ldk, N,
                        f.Linv, f.LinvT);
