@@ -51,6 +51,21 @@ __device__ __forceinline__ double2_t ld_f64x2(const double *p, int coh) {
   return v;
 }
 
+__device__ __forceinline__ void st_f64(double *p, double v, int coh) {
+  if (coh)
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // write-through
+  else
+    *p = v;
+}
+__device__ __forceinline__ void st_f64x2(double *p, double2_t v, int coh) {
+  if (coh) {
+    __hip_atomic_store(p, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(p + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else {
+    *reinterpret_cast<double2_t *>(p) = v;
+  }
+}
+
 // 1 / d to within an ulp or two: v_rcp_f64 seed + two Newton steps (5 dependent ops
 // instead of the ~12 of an IEEE-correct division; the pivots only enter through
 // products, which the 1e-10 iterate tolerance covers with 5 digits to spare)
@@ -210,7 +225,7 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
               double2_t w;
               w.x = x[k];
               w.y = x[k + 1];
-              *reinterpret_cast<double2_t *>(wp + k) = w;
+              st_f64x2(wp + k, w, coh);
             }
           }
         }
@@ -251,18 +266,18 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
     if (r < nrows) {
       const double2_t v = *reinterpret_cast<const double2_t *>(&M[64 + row][c2]);
       double *dst = K + (int64_t)r * ldk + c0 + c2;
-      if (c2 + 1 < nb) *reinterpret_cast<double2_t *>(dst) = v;
-      else if (c2 < nb) dst[0] = v.x;
+      if (c2 + 1 < nb) st_f64x2(dst, v, coh);
+      else if (c2 < nb) st_f64(dst, v.x, coh);
     }
   }
   if (wg == 0) {
     for (int p = tid; p < 64 * 64; p += 256) {
       const int row = p >> 6, c = p & 63;
-      if (row < nb && c <= row) K[(int64_t)(c0 + row) * ldk + c0 + c] = M[row][c];
+      if (row < nb && c <= row) st_f64(K + (int64_t)(c0 + row) * ldk + c0 + c, M[row][c], coh);
     }
     if (tid < nb) {
-      dvec[c0 + tid] = dD[tid];
-      dinv[c0 + tid] = dI[tid];
+      st_f64(dvec + c0 + tid, dD[tid], coh);
+      st_f64(dinv + c0 + tid, dI[tid], coh);
     }
     if (wave == 0) {
       const unsigned long long negs = __ballot(lane < nb && dD[lane] < 0.0);
@@ -435,7 +450,7 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, c
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = i0 + wr * WM + mi * 16 + l4 + 4 * r;
-        if (i < nrows && j < colEnd && j <= i) K[(int64_t)i * ldk + j] = acc[mi][nj][r];
+        if (i < nrows && j < colEnd && j <= i) st_f64(K + (int64_t)i * ldk + j, acc[mi][nj][r], coh);
       }
     }
   }
