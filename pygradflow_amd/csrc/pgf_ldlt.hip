@@ -823,7 +823,7 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
   // panels of block i + 1; PGF_COHERENT (default 1 with look-ahead): stream-A kernels and
   // (bit 1) the bulk kernel load with system scope, see ld_f64
   const bool la = getenv("PGF_LOOKAHEAD") != nullptr;
-  const int cohm = la ? (getenv("PGF_COHERENT") ? atoi(getenv("PGF_COHERENT")) : 1) : 0;
+  const int cohm = getenv("PGF_COHERENT") ? atoi(getenv("PGF_COHERENT")) : 0;
   const int cohA = cohm & 1, cohB = (cohm >> 1) & 1;
   hipStream_t sB = la ? f.stream2 : f.stream;
   int evi = 0;
