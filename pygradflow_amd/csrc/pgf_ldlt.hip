@@ -842,6 +842,14 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
     (void)hipEventRecord(ev0, sA);
     (void)hipStreamWaitEvent(sB, ev0, 0);
   }
+  const int la_dbg = getenv("PGF_LA_DEBUG") ? atoi(getenv("PGF_LA_DEBUG")) : 0;
+  auto self_fence = [&]() {  // experiment: explicit in-stream edge between consecutive kernels
+    if (la_dbg == 8) {
+      hipEvent_t ev = next_event();
+      (void)hipEventRecord(ev, sA);
+      (void)hipStreamWaitEvent(sA, ev, 0);
+    }
+  };
   const int skip = (getenv("PGF_SKIP") ? atoi(getenv("PGF_SKIP")) : 0) | (cohA << 3);
   // filler tiles in the panel launches: correct, but not yet a win (the panel's 87 KB of
   // LDS leaves one filler workgroup per CU, and the tile kernel needs several per SIMD)
@@ -899,8 +907,10 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
                            (int64_t)OB, c0 - ob0, N, nrows, c0, f.dvec, f.dinv, f.flags, skip);
       }
       const int c1 = c0 + PGF_NB;
+      self_fence();
       if (c1 < obEnd)  // inner update: the rest of this outer block's columns, K = 64
         launch_update(f, sA, Wb + (c0 - ob0), OB, N, nrows, c1, c1, obEnd, c0, PGF_NB, p, cohA);
+      self_fence();
     }
     pend.active = false;
     if (obEnd < N) {
