@@ -843,8 +843,13 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
     (void)hipStreamWaitEvent(sB, ev0, 0);
   }
   const int la_dbg = getenv("PGF_LA_DEBUG") ? atoi(getenv("PGF_LA_DEBUG")) : 0;
-  auto self_fence = [&]() {  // experiment: explicit in-stream edge between consecutive kernels
-    if (la_dbg == 8) {
+  // With a second queue active, consecutive kernels of ONE stream were observed to overlap
+  // (the last workgroups of an inner update still running when the next panel started:
+  // wrong factors, periodic in 8 workgroups).  An explicit record + wait on the same stream
+  // between dependent launches restores the in-order semantics; without look-ahead (one
+  // queue) it is not needed.
+  auto self_fence = [&]() {
+    if (la && la_dbg != 9) {
       hipEvent_t ev = next_event();
       (void)hipEventRecord(ev, sA);
       (void)hipStreamWaitEvent(sA, ev, 0);
@@ -918,6 +923,7 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
       const int nextEnd = std::min(obEnd + OB, N);
       if (la && b_pending) (void)hipStreamWaitEvent(sA, ev_b_done, 0);  // RMW order
       launch_update(f, sA, Wb, OB, N, nrows, obEnd, obEnd, nextEnd, ob0, KB, p, cohA);
+      self_fence();
       if (nextEnd < N) {
         if (la) {
           hipEvent_t ev_a = next_event();
@@ -943,6 +949,7 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
     }
   }
   if (la && b_pending) (void)hipStreamWaitEvent(sA, ev_b_done, 0);
+  self_fence();
   if (N > 0)
     hipLaunchKernelGGL(k_inv_diag_blocks, dim3((N + 63) / 64), dim3(64), 0, sA, f.K, f.ldk, N,
                        f.Linv, f.LinvT);
