@@ -195,6 +195,8 @@ def main():
         dn.residual_norm(norms_local.data_ptr())
         if dist is not None:
             dist.all_gather_into_tensor(norms_all, norms_local)  # the one collective / step
+            # keep one queue active at a time for the solver (look-ahead)
+            torch.cuda.current_stream(dev).synchronize()
 
     def fence():
         torch.cuda.synchronize(dev)

@@ -47,6 +47,8 @@ def gather_residual_norms(local_norms, num_instances: int, group=None):
     send[: local_norms.numel()] = local_norms
     out = torch.empty(cap * world, dtype=torch.float64, device=local_norms.device)
     dist.all_gather_into_tensor(out, send, group=group)
+    if out.is_cuda:  # the solver's queue should not run beside the collective's
+        torch.cuda.current_stream(out.device).synchronize()
     # drop the padding of short shards
     keep = []
     for r in range(world):
