@@ -467,6 +467,259 @@ __global__ __launch_bounds__(64 * WR * WC) void k_ldlt_update(
   update_tile<BM, BN, BK, WR, WC, DB>(smem, i0, j0, K, ldk, W, ldw, N, nrows, colEnd, kc0, KB);
 }
 
+// ------------------------------------------------------------------ wide panel kernel
+// Same algorithm as panel_body, generalised to a PW-column panel (PW = 128: half as many
+// panel launches and two of three inner updates per outer block disappear) with OWN rows
+// per workgroup.  The PW x PW diagonal block is kept in LDS as a packed lower trapezoid:
+// row-tile ti (16 rows) stores 16 (ti + 1) + 2 doubles per row, so the 128 x 128 block
+// takes 76 KB instead of 133 KB and leaves room for the own rows and W; the +2 padding
+// keeps MFMA fragment reads conflict-free (row strides of 4 or 36 dwords mod 64).
+template <int PW, int OWN>
+struct PanelLayout {
+  static constexpr int CT = PW / 16;
+  static constexpr int R = PW + OWN;
+  static constexpr int RT = R / 16;
+  static constexpr int DIAG = 128 * CT * (CT + 1) + 32 * CT;
+  static constexpr int OWN_LD = PW + 2;
+  static constexpr int OWND = OWN * OWN_LD;
+  static constexpr int WTD = R * 18;
+  static constexpr int SMEM = (DIAG + OWND + WTD + 2 * PW) * 8 + 16;
+  __device__ __forceinline__ static int off(int row, int col) {
+    if (row < PW) {
+      const int ti = row >> 4;
+      return 128 * ti * (ti + 1) + 32 * ti + (row & 15) * (16 * (ti + 1) + 2) + col;
+    }
+    return DIAG + (row - PW) * OWN_LD + col;
+  }
+};
+
+template <int PW, int OWN>
+__device__ __forceinline__ void panel_body2(unsigned char *smem, const int wg,
+                                            double *__restrict__ K, int64_t ldk,
+                                            double *__restrict__ W, int64_t ldw, int wofs, int N,
+                                            int nrows, int c0, double *__restrict__ dvec,
+                                            double *__restrict__ dinv, int *__restrict__ flags,
+                                            int skip) {
+  using LY = PanelLayout<PW, OWN>;
+  constexpr int CT = LY::CT, R = LY::R, RT = LY::RT;
+  double *M = reinterpret_cast<double *>(smem);
+  double(*Wt)[18] = reinterpret_cast<double(*)[18]>(M + LY::DIAG + LY::OWND);
+  double *dD = M + LY::DIAG + LY::OWND + LY::WTD;
+  double *dI = dD + PW;
+  int &s_bad = *reinterpret_cast<int *>(dI + PW);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int nb = min(PW, N - c0);
+  const int rbase = c0 + nb + wg * OWN;  // first own row (global)
+  const int coh = (skip >> 3) & 1;
+  if (tid == 0) s_bad = 0;
+
+  // ---- load the diagonal block (lower trapezoid; identity padding beyond nb) ...
+  {
+    constexpr int HP = PW / 2;             // 16-byte pieces per full row
+    constexpr int DP = PW * HP / 256;      // per lane
+    double2_t v[DP];
+#pragma unroll
+    for (int q = 0; q < DP; ++q) {
+      const int p = q * 256 + tid;
+      const int row = p / HP, c2 = (p % HP) * 2;
+      double2_t t = (double2_t){0.0, 0.0};
+      if (c2 < 16 * ((row >> 4) + 1)) {
+        if (row < nb) {
+          const double *src = K + (int64_t)(c0 + row) * ldk + c0 + c2;
+          if (c2 + 1 <= row) t = ld_f64x2(src, coh);
+          else if (c2 <= row) t.x = ld_f64(src, coh);
+        } else {
+          if (c2 == row) t.x = 1.0;
+          if (c2 + 1 == row) t.y = 1.0;
+        }
+      }
+      v[q] = t;
+    }
+#pragma unroll
+    for (int q = 0; q < DP; ++q) {
+      const int p = q * 256 + tid;
+      const int row = p / HP, c2 = (p % HP) * 2;
+      if (c2 < 16 * ((row >> 4) + 1)) *reinterpret_cast<double2_t *>(&M[LY::off(row, c2)]) = v[q];
+    }
+    // ... and the own rows
+    constexpr int OP = OWN * HP / 256;
+    double2_t u[OP];
+#pragma unroll
+    for (int q = 0; q < OP; ++q) {
+      const int p = q * 256 + tid;
+      const int row = p / HP, c2 = (p % HP) * 2;
+      const int r = rbase + row;
+      double2_t t = (double2_t){0.0, 0.0};
+      if (r < nrows) {
+        const double *src = K + (int64_t)r * ldk + c0 + c2;
+        if (c2 + 1 < nb) t = ld_f64x2(src, coh);
+        else if (c2 < nb) t.x = ld_f64(src, coh);
+      }
+      u[q] = t;
+    }
+#pragma unroll
+    for (int q = 0; q < OP; ++q) {
+      const int p = q * 256 + tid;
+      *reinterpret_cast<double2_t *>(&M[LY::off(PW + p / HP, (p % HP) * 2)]) = u[q];
+    }
+  }
+  __syncthreads();
+
+  for (int sb = 0; sb < CT; ++sb) {
+    const int cb = sb * 16;
+    // ---- (a) 16 x 16 diagonal tile: wavefront 0, lane (l & 15) <-> row
+    if (wave == 0 && !(skip & 1)) {
+      double a[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) a[k] = M[LY::off(cb + l15, cb + k)];
+      double d_mine = 1.0, di_mine = 1.0;
+      int bad_any = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const double d = lane_bcast(a[j], j);
+        const bool bad = (d == 0.0) || !(fabs(d) <= 1.79e308);
+        const double di = bad ? 0.0 : fast_recip(d);
+        bad_any |= (bad && (cb + j) < nb) ? 1 : 0;
+        if (l15 == j) {
+          d_mine = d;
+          di_mine = di;
+        }
+        const double l = a[j] * di;
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) a[k] = fma(-l, lane_bcast(a[j], k), a[k]);
+        a[j] = l;
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (k < lane) M[LY::off(cb + lane, cb + k)] = a[k];
+        M[LY::off(cb + lane, cb + lane)] = d_mine;
+        dD[cb + lane] = d_mine;
+        dI[cb + lane] = di_mine;
+        if (lane == 0 && bad_any) s_bad = 1;
+      }
+    }
+    __syncthreads();
+    // ---- (b) rows below the tile: substitution, one lane per row
+    {
+      const int row = cb + 16 + wave * 64 + lane;
+      if (row < R && !(skip & 2)) {
+        double x[16];
+        const double *xr = &M[LY::off(row, cb)];
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+          const double2_t v = *reinterpret_cast<const double2_t *>(xr + k);
+          x[k] = v.x;
+          x[k + 1] = v.y;
+        }
+#pragma unroll
+        for (int t = 0; t < 15; ++t) {
+          const double xt = x[t];
+#pragma unroll
+          for (int j = t + 1; j < 16; ++j) x[j] = fma(-xt, M[LY::off(cb + j, cb + t)], x[j]);
+        }
+        double *xw = &M[LY::off(row, cb)];
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+          double2_t w, l;
+          w.x = x[k];
+          w.y = x[k + 1];
+          l.x = x[k] * dI[cb + k];
+          l.y = x[k + 1] * dI[cb + k + 1];
+          *reinterpret_cast<double2_t *>(&Wt[row][k]) = w;
+          *reinterpret_cast<double2_t *>(xw + k) = l;
+        }
+        if (row >= PW) {
+          const int r = rbase + row - PW;
+          if (r < nrows) {
+            double *wp = W + (int64_t)r * ldw + wofs + cb;
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) {
+              double2_t w;
+              w.x = x[k];
+              w.y = x[k + 1];
+              st_f64x2(wp + k, w, coh);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- (c) tiles to the right: M[ti][tj] -= W[ti] L[tj]^T, tj in (sb, CT), ti in [tj, RT)
+    if (sb + 1 < CT && !(skip & 4)) {
+      int total = 0;
+      for (int tj = sb + 1; tj < CT; ++tj) total += RT - tj;
+      for (int e0 = wave; e0 < total; e0 += 4) {
+        int e = e0, tj = sb + 1;
+        while (e >= RT - tj) {
+          e -= RT - tj;
+          ++tj;
+        }
+        const int ti = tj + e;
+        double4_t acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = M[LY::off(ti * 16 + l4 + 4 * r, tj * 16 + l15)];
+#pragma unroll
+        for (int ks = 0; ks < 16; ks += 4) {
+          const double av = -Wt[ti * 16 + l15][ks + l4];
+          const double bv = M[LY::off(tj * 16 + l15, cb + ks + l4)];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) M[LY::off(ti * 16 + l4 + 4 * r, tj * 16 + l15)] = acc[r];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- write back: own rows (L), and by workgroup 0 the factored diagonal block
+  {
+    constexpr int HP = PW / 2;
+    for (int p = tid; p < OWN * HP; p += 256) {
+      const int row = p / HP, c2 = (p % HP) * 2;
+      const int r = rbase + row;
+      if (r < nrows) {
+        const double2_t v = *reinterpret_cast<const double2_t *>(&M[LY::off(PW + row, c2)]);
+        double *dst = K + (int64_t)r * ldk + c0 + c2;
+        if (c2 + 1 < nb) st_f64x2(dst, v, coh);
+        else if (c2 < nb) st_f64(dst, v.x, coh);
+      }
+    }
+  }
+  if (wg == 0) {
+    for (int p = tid; p < PW * PW; p += 256) {
+      const int row = p / PW, c = p % PW;
+      if (row < nb && c <= row) st_f64(K + (int64_t)(c0 + row) * ldk + c0 + c, M[LY::off(row, c)], coh);
+    }
+    for (int i = tid; i < nb; i += 256) {
+      st_f64(dvec + c0 + i, dD[i], coh);
+      st_f64(dinv + c0 + i, dI[i], coh);
+    }
+    if (wave == 0) {
+      int neg = 0;
+      for (int i = lane; i < nb; i += 64) neg += (dD[i] < 0.0) ? 1 : 0;
+      for (int o = 32; o > 0; o >>= 1) neg += __shfl_down(neg, o);
+      if (lane == 0) {
+        if (s_bad) atomicOr(&flags[0], 1);
+        if (neg) atomicAdd(&flags[1], neg);
+      }
+    }
+  }
+}
+
+template <int PW, int OWN>
+__global__ __launch_bounds__(256) void k_ldlt_panel2(double *__restrict__ K, int64_t ldk,
+                                                     double *__restrict__ W, int64_t ldw, int wofs,
+                                                     int N, int nrows, int c0,
+                                                     double *__restrict__ dvec,
+                                                     double *__restrict__ dinv,
+                                                     int *__restrict__ flags, int skip) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[PanelLayout<PW, OWN>::SMEM];
+  panel_body2<PW, OWN>(smem, blockIdx.x, K, ldk, W, ldw, wofs, N, nrows, c0, dvec, dinv, flags,
+                       skip);
+}
+
 template <int NB>
 __global__ __launch_bounds__(256) void k_ldlt_panel(double *__restrict__ K, int64_t ldk,
                                                     double *__restrict__ W, int64_t ldw, int wofs,
@@ -843,6 +1096,11 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
     (void)hipStreamWaitEvent(sB, ev0, 0);
   }
   const int la_dbg = getenv("PGF_LA_DEBUG") ? atoi(getenv("PGF_LA_DEBUG")) : 0;
+  // panel width: 128 (wide kernel, 32 own rows per workgroup) or 64
+  const int pw_env = getenv("PGF_PW") ? atoi(getenv("PGF_PW")) : 128;
+  const bool pnl2 = getenv("PGF_PANEL2") != nullptr;  // 64-wide panel through the new body
+  const int PWh = (pw_env == 128 && OB % 128 == 0 && getenv("PGF_FUSE") == nullptr) ? 128 : 64;
+  const int OWNh = (PWh == 128) ? 32 : 64;
   // With a second queue active, consecutive kernels of ONE stream were observed to overlap
   // (the last workgroups of an inner update still running when the next panel started:
   // wrong factors, periodic in 8 workgroups).  An explicit record + wait on the same stream
@@ -869,11 +1127,11 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
   for (int ob0 = 0; ob0 < N; ob0 += OB, buf ^= 1) {
     const int obEnd = std::min(ob0 + OB, N);
     double *Wb = f.W + (size_t)buf * f.wstride;
-    const int npanels = (obEnd - ob0 + PGF_NB - 1) / PGF_NB;
+    const int npanels = (obEnd - ob0 + PWh - 1) / PWh;
     int k = 0;
-    for (int c0 = ob0; c0 < obEnd; c0 += PGF_NB, ++k) {
-      const int below = nrows - std::min(c0 + PGF_NB, N);
-      const int npw = std::max(1, (below + 63) / 64);
+    for (int c0 = ob0; c0 < obEnd; c0 += PWh, ++k) {
+      const int below = nrows - std::min(c0 + PWh, N);
+      const int npw = std::max(1, (below + OWNh - 1) / OWNh);
       const int remaining = pend.active ? pend.total - pend.done : 0;
       if (remaining > 0) {
         const int share = (remaining + (npanels - k) - 1) / (npanels - k);
@@ -907,14 +1165,20 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
           p->update_flops.push_back(2.0 * cnt * pend.KB);
         }
         pend.done += share;
+      } else if (PWh == 128) {
+        hipLaunchKernelGGL((k_ldlt_panel2<128, 32>), dim3(npw), dim3(256), 0, sA, f.K, f.ldk, Wb,
+                           (int64_t)OB, c0 - ob0, N, nrows, c0, f.dvec, f.dinv, f.flags, skip);
+      } else if (pnl2) {
+        hipLaunchKernelGGL((k_ldlt_panel2<64, 64>), dim3(npw), dim3(256), 0, sA, f.K, f.ldk, Wb,
+                           (int64_t)OB, c0 - ob0, N, nrows, c0, f.dvec, f.dinv, f.flags, skip);
       } else {
         hipLaunchKernelGGL(k_ldlt_panel<PGF_NB>, dim3(npw), dim3(256), 0, sA, f.K, f.ldk, Wb,
                            (int64_t)OB, c0 - ob0, N, nrows, c0, f.dvec, f.dinv, f.flags, skip);
       }
-      const int c1 = c0 + PGF_NB;
+      const int c1 = c0 + PWh;
       self_fence();
-      if (c1 < obEnd)  // inner update: the rest of this outer block's columns, K = 64
-        launch_update(f, sA, Wb + (c0 - ob0), OB, N, nrows, c1, c1, obEnd, c0, PGF_NB, p, cohA);
+      if (c1 < obEnd)  // inner update: the rest of this outer block's columns, K = panel width
+        launch_update(f, sA, Wb + (c0 - ob0), OB, N, nrows, c1, c1, obEnd, c0, PWh, p, cohA);
       self_fence();
     }
     pend.active = false;
