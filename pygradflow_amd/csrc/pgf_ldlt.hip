@@ -344,9 +344,8 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, c
   }
 
   // staging map: piece p = q*256 + tid -> row p / PPR, two doubles at column (p % PPR)*2
-  double2_t pa2[2][PA], pb2[2][PB];
-  auto fetch = [&](int kk, int rs = 0) {
-    double2_t *pa = pa2[rs], *pb = pb2[rs];
+  double2_t pa[PA], pb[PB];
+  auto fetch = [&](int kk, int = 0) {
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
       const int p = q * NT + tid;
@@ -367,8 +366,7 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, c
       pb[q] = vb;
     }
   };
-  auto stage = [&](int buf, int rs = 0) {
-    double2_t *pa = pa2[rs], *pb = pb2[rs];
+  auto stage = [&](int buf, int = 0) {
     double(*As)[LD] = reinterpret_cast<double(*)[LD]>(smem + buf * STAGE);
     double(*Bs)[LD] = reinterpret_cast<double(*)[LD]>(smem + buf * STAGE + BM * LD * 8);
     // negate here, not at the fetch: touching the loaded value there would make the
@@ -404,17 +402,59 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, c
 
   fetch(0);
   if (DB == 2) {
-    // two LDS stages and TWO chunks in flight (two register sets): the loads of chunk c+2
-    // are issued before chunk c is computed, so a fetch has two compute phases to land
+    // two LDS stages and TWO chunks in flight, in two STATICALLY named register sets (a
+    // runtime-indexed set goes to scratch): the loads of chunk c+2 are issued before chunk c
+    // is computed, so every fetch has two compute phases to land.
+    double2_t qa[PA], qb[PB];  // second register set (the first is pa2[0] / pb2[0])
+    auto fetch1 = [&](int kk) {
+#pragma unroll
+      for (int q = 0; q < PA; ++q) {
+        const int p = q * NT + tid;
+        const int row = p / PPR, kofs = (p % PPR) * 2;
+        const int gi = i0 + row;
+        double2_t va = (double2_t){0.0, 0.0};
+        if (gi < nrows) va = ld_f64x2(W + (int64_t)gi * ldw + kk + kofs, coh);
+        qa[q] = va;
+      }
+#pragma unroll
+      for (int q = 0; q < PB; ++q) {
+        const int p = q * NT + tid;
+        const int row = p / PPR, kofs = (p % PPR) * 2;
+        const int gj = j0 + row;
+        double2_t vb = (double2_t){0.0, 0.0};
+        if (gj < colEnd) vb = ld_f64x2(K + (int64_t)gj * ldk + kc0 + kk + kofs, coh);
+        qb[q] = vb;
+      }
+    };
+    auto stage1 = [&](int buf) {
+      double(*As)[LD] = reinterpret_cast<double(*)[LD]>(smem + buf * STAGE);
+      double(*Bs)[LD] = reinterpret_cast<double(*)[LD]>(smem + buf * STAGE + BM * LD * 8);
+#pragma unroll
+      for (int q = 0; q < PA; ++q) {
+        const int p = q * NT + tid;
+        *reinterpret_cast<double2_t *>(&As[p / PPR][(p % PPR) * 2]) = -qa[q];
+      }
+#pragma unroll
+      for (int q = 0; q < PB; ++q) {
+        const int p = q * NT + tid;
+        *reinterpret_cast<double2_t *>(&Bs[p / PPR][(p % PPR) * 2]) = qb[q];
+      }
+    };
     const int nc = KB / BK;
-    if (nc > 1) fetch(BK, 1);
+    if (nc > 1) fetch1(BK);
     stage(0, 0);
     __syncthreads();
-#pragma unroll 2
-    for (int c = 0; c < nc; ++c) {
-      if (c + 2 < nc) fetch((c + 2) * BK, c & 1);  // set c&1 was staged one iteration ago
-      compute(c & 1);
-      if (c + 1 < nc) stage((c + 1) & 1, (c + 1) & 1);
+    for (int c = 0; c < nc; c += 2) {
+      // even chunk c: LDS stage 0; set 1 holds chunk c+1 (in flight); set 0 is free
+      if (c + 2 < nc) fetch((c + 2) * BK, 0);
+      compute(0);
+      if (c + 1 < nc) stage1(1);
+      __syncthreads();
+      if (c + 1 >= nc) break;
+      // odd chunk c+1: LDS stage 1; set 0 holds chunk c+2 (in flight); set 1 is free
+      if (c + 3 < nc) fetch1((c + 3) * BK);
+      compute(1);
+      if (c + 2 < nc) stage(0, 0);
       __syncthreads();
     }
   } else if (DB) {
@@ -1097,7 +1137,7 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
   }
   const int la_dbg = getenv("PGF_LA_DEBUG") ? atoi(getenv("PGF_LA_DEBUG")) : 0;
   // panel width: 128 (wide kernel, 32 own rows per workgroup) or 64
-  const int pw_env = getenv("PGF_PW") ? atoi(getenv("PGF_PW")) : 128;
+  const int pw_env = getenv("PGF_PW") ? atoi(getenv("PGF_PW")) : 64;
   const bool pnl2 = getenv("PGF_PANEL2") != nullptr;  // 64-wide panel through the new body
   const int PWh = (pw_env == 128 && OB % 128 == 0 && getenv("PGF_FUSE") == nullptr) ? 128 : 64;
   const int OWNh = (PWh == 128) ? 32 : 64;
@@ -1297,13 +1337,13 @@ hipError_t ldlt_bench_update(int N, int KB, int variant, int reps, double *ms_ou
     switch (variant) {
       case 0: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2, 0); break;
       case 1: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2, 2); break;
-      case 2: PGF_LAUNCH_VARIANT(128, 128, 16, 4, 4, 1); break;
+      case 2: PGF_LAUNCH_VARIANT(128, 128, 16, 2, 2, 2); break;
       case 3: PGF_LAUNCH_VARIANT(128, 128, 16, 4, 4, 2); break;
-      case 4: PGF_LAUNCH_VARIANT(128, 128, 32, 4, 4, 2); break;
-      case 5: PGF_LAUNCH_VARIANT(128, 128, 16, 2, 4, 2); break;
+      case 4: PGF_LAUNCH_VARIANT(128, 128, 16, 2, 4, 2); break;
+      case 5: PGF_LAUNCH_VARIANT(128, 64, 16, 2, 2, 2); break;
       case 6: PGF_LAUNCH_VARIANT(128, 64, 16, 4, 2, 2); break;
-      case 7: PGF_LAUNCH_VARIANT(128, 64, 16, 2, 2, 2); break;
-      case 8: PGF_LAUNCH_VARIANT(256, 128, 16, 4, 4, 2); break;
+      case 7: PGF_LAUNCH_VARIANT(128, 128, 32, 2, 4, 2); break;
+      case 8: PGF_LAUNCH_VARIANT(64, 128, 16, 2, 2, 2); break;
       default: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2, 0); break;
     }
 #undef PGF_LAUNCH_VARIANT
