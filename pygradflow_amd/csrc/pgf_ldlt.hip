@@ -309,7 +309,7 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, c
                                             double *__restrict__ K, int64_t ldk,
                                             const double *__restrict__ W, int64_t ldw, int N,
                                             int nrows, int colEnd, int kc0, int KBc) {
-  const int KB = KBc & 0xFFFFF;        // K-depth (bit 21: XCD-aware order, handled by the kernel)
+  const int KB = KBc & 0xFFFFF;        // K-depth
   const int coh = (KBc >> 20) & 1;     // bit 20: system-scope loads (look-ahead schedule)
   constexpr int NT = 64 * WR * WC;           // threads per workgroup
   constexpr int WM = BM / WR, WN = BN / WC;  // rows / columns per wavefront
@@ -501,18 +501,9 @@ __global__ __launch_bounds__(64 * WR * WC) void k_ldlt_update(
     double *__restrict__ K, int64_t ldk, const double *__restrict__ W, int64_t ldw, int N,
     int nrows, int row0, int col0, int colEnd, int kc0, int KB) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[(DB ? 2 : 1) * (BM + BN) * (BK + 2) * 8];
-  // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs, so
-  // give each XCD a contiguous run of tile ids (whole tile rows share the W rows and most of
-  // the L rows in that XCD's L2) instead of every 8th tile.  Bijective for any grid size.
-  int bx = blockIdx.x, by = blockIdx.y;
-  if (KB & (1 << 21)) {
-    const int nwg = gridDim.x * gridDim.y;
-    const int orig = blockIdx.y * gridDim.x + blockIdx.x;
-    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    by = id / gridDim.x;
-    bx = id - by * gridDim.x;
-  }
+  // (an XCD-contiguous tile order was tried and loses badly here: on the triangular domain
+  // it starves the XCDs that get the short upper tile rows, 42 -> 24 TFLOP/s)
+  const int bx = blockIdx.x, by = blockIdx.y;
   const int i0 = row0 + by * BM;
   const int j0 = col0 + bx * BN;
   if (j0 > i0 + BM - 1) return;  // tile entirely above the diagonal
@@ -1346,8 +1337,8 @@ hipError_t ldlt_bench_update(int N, int KB, int variant, int reps, double *ms_ou
   hipLaunchKernelGGL((k_ldlt_update<BM_, BN_, BK_, WR_, WC_, DB_>),                             \
                      dim3((N + BN_ - 1) / BN_, (N + BM_ - 1) / BM_), dim3(64 * WR_ * WC_), 0, s, \
                      f.K, f.ldk, f.W, (int64_t)KB, Nt, Nt, KB, KB, Nt, 0, KBx)
-    const int KBx = KB | ((variant >= 100) ? (1 << 21) : 0);
-    switch (variant % 100) {
+    const int KBx = KB;
+    switch (variant) {
       case 0: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2, 0); break;
       case 1: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2, 2); break;
       case 2: PGF_LAUNCH_VARIANT(128, 128, 16, 2, 2, 2); break;
