@@ -30,7 +30,7 @@ def __getattr__(name):
 
         return HipLinearSolver
     if name in ("newton_method", "newton_steps", "DeviceNewton", "SimplifiedNewtonMethod",
-                "FullNewtonMethod", "ActiveSetNewtonMethod"):
+                "FullNewtonMethod", "ActiveSetNewtonMethod", "GlobalizedNewtonMethod"):
         from . import newton
 
         return getattr(newton, name)

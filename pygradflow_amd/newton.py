@@ -87,6 +87,49 @@ class ActiveSetNewtonMethod(NewtonMethod):
         return self.step_solver.solve(iterate)
 
 
+class GlobalizedNewtonMethod(NewtonMethod):
+    """Newton step followed by an Armijo line search on 1/2 ||F||^2 (reference
+    newton.py:218-304).  Host-side policy: residuals, masks and the linear solve come from
+    the step solver; the generalised Jacobian for the directional derivative is assembled on
+    the host (off the hot path, as in the reference's own TODO at :250-252)."""
+
+    MAX_BACKTRACKS = 30
+
+    def _set_iterate(self, iterate):
+        self.step_solver.update_derivs(iterate)
+        mask = self.func.compute_active_set(iterate, self.rho, self.tau)
+        self.step_solver.update_active_set(mask)
+
+    def step(self, iterate):
+        from .step_solver import StepResult
+
+        params = iterate.params
+        n = self.problem.num_vars
+        self._set_iterate(iterate)
+        # the reference solves at the OUTER iterate here (newton.py:248); kept as is
+        full = self.step_solver.solve(self.orig_iterate)
+        value = self.func.value_at(iterate, self.rho)
+        merit = 0.5 * np.dot(value, value)
+        if merit <= params.newton_tol:
+            return full
+        grad = self.func.deriv_at(iterate, self.rho).T @ value
+        slope = np.dot(grad[:n], full.dx) + np.dot(grad[n:], full.dy)
+        alpha, dx, dy = 1.0, full.dx, full.dy
+        for _ in range(self.MAX_BACKTRACKS):
+            trial = type(iterate)(self.problem, params, iterate.x - dx, iterate.y - dy, iterate.eval)
+            tv = self.func.value_at(trial, self.rho)
+            tm = 0.5 * np.dot(tv, tv)
+            if tm <= params.newton_tol or tm <= merit + 1e-4 * alpha * slope:
+                break
+            alpha *= 0.5
+            dx, dy = alpha * full.dx, alpha * full.dy
+        else:
+            raise Exception("Line search failed to converge")
+        result = StepResult(self.orig_iterate, dx, dy, active_set=None, rcond=None)
+        result.active_set = self.func.compute_active_set(result.iterate, self.rho, self.tau)
+        return result
+
+
 def make_step_solver(problem, params, iterate, dt, rho):
     """Reference factory ``step_solver`` (step/solver/__init__.py:12-31): honours the
     ``params.step_solver`` hook, defaults to the HIP solver (Symmetric formulation)."""
@@ -112,7 +155,9 @@ def newton_method(problem, params, iterate, dt, rho, tau=None):
         return FullNewtonMethod(problem, iterate, dt, rho, solver, tau)
     if kind == "ActiveSet":
         return ActiveSetNewtonMethod(problem, iterate, dt, rho, solver, tau)
-    raise NotImplementedError(f"newton_type {kind} is not on the HIP hot path yet (SURVEY 8f)")
+    if kind == "Globalized":
+        return GlobalizedNewtonMethod(problem, iterate, dt, rho, solver, tau)
+    raise ValueError(f"unknown newton_type {kind}")
 
 
 def newton_steps(problem, params, orig_iterate, dt, rho, tau=None):

@@ -96,6 +96,20 @@ class StepResult:
         self.xn = xn
         self._yn = yn
         self._diff = diff
+        if xn is None:
+            # host construction (line search of the Globalized policy): clip like the
+            # reference does (step_solver.py:25-48)
+            lb, ub = orig_iterate.problem.var_lb, orig_iterate.problem.var_ub
+            x = orig_iterate.x
+            xn = x - dx
+            dx = np.copy(dx)
+            low = xn < lb
+            xn[low] = lb[low]
+            dx[low] = x[low] - lb[low]
+            up = xn > ub
+            xn[up] = ub[up]
+            dx[up] = x[up] - ub[up]
+            self.dx, self.xn = dx, xn
 
     @functools.cached_property
     def iterate(self):
@@ -359,8 +373,12 @@ class HipStepSolver:
             raise StepSolverError(str(e)) from e
         self.solver = _DeviceFactorView(self)
         rcond = None
-        if getattr(params, "report_rcond", False):
-            rcond = None  # condition estimate: SURVEY 8f rank 3, not on the path yet
+        if getattr(params, "report_rcond", False) and not self.sparse:
+            from .cond_estimate import estimate_rcond
+
+            Kl = self.kkt_matrix()
+            Kfull = Kl + np.tril(Kl, -1).T
+            rcond = estimate_rcond(Kfull, self.solver, params)
         return StepResult(iterate, dx, dy, self.active_set, rcond, xn=xn, yn=yn, diff=diff.value)
 
 

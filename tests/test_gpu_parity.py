@@ -339,3 +339,30 @@ def test_banded_box_qp_mask_churn(pgf):
         assert np.array_equal(dn.mask(), rec["mask"]), k
         assert G.rel_err(x, rec["xn"]) <= TOL, k
     dn.close()
+
+
+# ------------------------------------------------------------------ section 8(f) rows
+@pytest.mark.parametrize("name", ["extras_quartic_n12_m4", "extras_dense_qp_boxed_n96_m24"])
+def test_globalized_policy_and_rcond(pgf, name):
+    """GlobalizedNewtonMethod (reference newton.py:218-304) and the randomised condition
+    estimate behind Params.report_rcond (step/cond_estimate.py) against reference vectors."""
+    case = G.load_case(name)
+    problem = G.rebuild_problem(case)
+    dt, rho = float(case["dt"]), float(case["rho"])
+    params = pgf.Params(newton_type="Globalized", step_solver=pgf.HipStepSolver)
+    orig = pgf.Iterate(problem, params, case["x0"], case["y0"])
+    gen = pgf.newton_steps(problem, params, orig, dt, rho)
+    for k in range(int(case["glob_steps"])):
+        pre = f"Globalized/{k}/"
+        step = next(gen)
+        assert np.array_equal(step.active_set, case[pre + "mask"]), k
+        assert G.rel_err(step.iterate.x, case[pre + "xn"]) <= TOL, k
+        assert G.rel_err(step.iterate.y, case[pre + "yn"]) <= TOL, k
+        assert G.rel_err(step.dx, case[pre + "dx"]) <= TOL, k
+    params = pgf.Params(newton_type="Full", step_solver=pgf.HipStepSolver, report_rcond=True)
+    orig = pgf.Iterate(problem, params, case["x0"], case["y0"])
+    gen = pgf.newton_steps(problem, params, orig, dt, rho)
+    for k in range(int(case["steps"])):
+        step = next(gen)
+        ref = float(case[f"rcond/{k}"])
+        assert step.rcond is not None and abs(step.rcond - ref) <= 1e-8 * ref, (k, step.rcond, ref)

@@ -121,6 +121,39 @@ def run_case(name, problem, x0, y0, dt, rho, steps, tau=None, policies=POLICIES,
     print(f"{name}: n={n} m={m} steps={steps} margin={min_margin:.2e}")
 
 
+def run_extras(name, problem, x0, y0, dt, rho, steps, store_problem, glob_steps=None):
+    """Section 8(f) rows on the Newton surface: GlobalizedNewtonMethod trajectories
+    (newton.py:218-304) and the randomised condition estimate (step/cond_estimate.py)."""
+    glob_steps = steps if glob_steps is None else glob_steps
+    out = dict(n=problem.num_vars, m=problem.num_cons, dt=dt, rho=rho, steps=steps, glob_steps=glob_steps,
+               x0=np.asarray(x0, float), y0=np.asarray(y0, float),
+               var_lb=problem.var_lb, var_ub=problem.var_ub)
+    for k, v in store_problem.items():
+        out["problem/" + k] = v
+    params = Params(newton_type=NewtonType.Globalized)
+    orig = Iterate(problem, params, np.asarray(x0, float), np.asarray(y0, float))
+    method = newton_method(problem, params, orig, dt, rho)
+    it = orig
+    for k in range(glob_steps):
+        step = method.step(it)
+        pre = f"Globalized/{k}/"
+        out[pre + "x"], out[pre + "y"] = it.x, it.y
+        out[pre + "dx"], out[pre + "dy"] = step.dx, step.dy
+        out[pre + "xn"], out[pre + "yn"] = step.iterate.x, step.iterate.y
+        out[pre + "mask"] = np.asarray(step.active_set)
+        it = step.iterate
+    params = Params(newton_type=NewtonType.Full, report_rcond=True)
+    orig = Iterate(problem, params, np.asarray(x0, float), np.asarray(y0, float))
+    method = newton_method(problem, params, orig, dt, rho)
+    it = orig
+    for k in range(steps):
+        step = method.step(it)
+        out[f"rcond/{k}"] = step.rcond
+        it = step.iterate
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: extras written (rcond {out['rcond/0']:.3e})")
+
+
 def qp_store(prob):
     return dict(kind="lq", Q=prob.hess_dense(), q=prob.q, A=prob.jac_dense(), b=prob.b)
 
@@ -154,9 +187,20 @@ def linear_solver_cases():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    from tests.pygradflow.hs71 import HS71  # reference fixtures
-    from tests.pygradflow.rosenbrock import Rosenbrock
-    from tests.pygradflow.tame import Tame
+    # the reference's own fixture problems, loaded by path (this repository has a `tests`
+    # package of its own, which would shadow the reference's)
+    import importlib.util
+
+    def _ref_fixture(mod, cls):
+        path = os.path.join(REF, "tests", "pygradflow", mod + ".py")
+        spec = importlib.util.spec_from_file_location("_ref_fixture_" + mod, path)
+        module = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(module)
+        return getattr(module, cls)
+
+    HS71 = _ref_fixture("hs71", "HS71")
+    Rosenbrock = _ref_fixture("rosenbrock", "Rosenbrock")
+    Tame = _ref_fixture("tame", "Tame")
 
     # reference test_solver.py:191-215 (one-step convergence, dt=10, rho=1)
     run_case("tame_dt10", Tame(), [0.0, 0.0], [0.0], 10.0, 1.0, 2)
@@ -203,6 +247,13 @@ def main():
     run_case("ocp_m40", o3, np.zeros(80), np.zeros(40), 1.0, 1.0, 3, store_problem=qp_store(o3))
     b5 = P.box_qp(256, seed=0)
     run_case("box_qp_n256", b5, np.zeros(256), [], 1.0, 1.0, 6, store_problem=qp_store(b5))
+
+    # the reference's Globalized policy solves at the OUTER iterate (newton.py:248), so its
+    # line search only survives one step on the nonlinear problem; three on the QP at dt=0.1
+    run_extras("extras_quartic_n12_m4", qn, x0, np.zeros(4), 0.1, 0.7, 3, quartic_store(qn),
+               glob_steps=1)
+    run_extras("extras_dense_qp_boxed_n96_m24", d2b, np.zeros(96), np.zeros(24), 0.1, 1.0, 3,
+               qp_store(d2b))
 
     linear_solver_cases()
 
