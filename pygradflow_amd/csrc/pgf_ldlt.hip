@@ -1228,6 +1228,12 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
     if (obEnd < N) {
       const int KB = obEnd - ob0;  // == OB here (only the last outer block may be short)
       const int nextEnd = std::min(obEnd + OB, N);
+      if (!la && !fuse) {
+        // one queue, no look-ahead: nothing is gained by splitting off the next block's
+        // columns -- update the whole trailing matrix in one (large, efficient) launch
+        launch_update(f, sA, Wb, OB, N, nrows, obEnd, obEnd, N, ob0, KB, p, 0);
+        continue;
+      }
       if (la && b_pending) (void)hipStreamWaitEvent(sA, ev_b_done, 0);  // RMW order
       launch_update(f, sA, Wb, OB, N, nrows, obEnd, obEnd, nextEnd, ob0, KB, p, cohA);
       self_fence();
