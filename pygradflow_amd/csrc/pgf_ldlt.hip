@@ -1354,6 +1354,8 @@ hipError_t ldlt_bench_update(int N, int KB, int variant, int reps, double *ms_ou
       case 6: PGF_LAUNCH_VARIANT(128, 64, 16, 4, 2, 2); break;
       case 7: PGF_LAUNCH_VARIANT(128, 128, 32, 2, 4, 2); break;
       case 8: PGF_LAUNCH_VARIANT(64, 128, 16, 2, 2, 2); break;
+      case 9: PGF_LAUNCH_VARIANT(64, 64, 64, 2, 2, 0); break;
+      case 10: PGF_LAUNCH_VARIANT(64, 64, 32, 2, 2, 0); break;
       default: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2, 0); break;
     }
 #undef PGF_LAUNCH_VARIANT
