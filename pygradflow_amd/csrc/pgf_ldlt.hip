@@ -510,6 +510,71 @@ __global__ __launch_bounds__(64 * WR * WC) void k_ldlt_update(
   update_tile<BM, BN, BK, WR, WC, DB>(smem, i0, j0, K, ldk, W, ldw, N, nrows, colEnd, kc0, KB);
 }
 
+// ------------------------------------------------------------------ 64-bit DPP helpers
+// gfx950 has 64-bit DPP with the row_newbcast control: the source operand is read from lane
+// L of the reader's own 16-lane row.  One v_fmac_f64_dpp therefore does
+//   acc += (value held by lane L of my row) * mult
+// which is exactly the rank-1 update of a 16 x 16 tile whose rows live on the 16 lanes of a
+// row -- no v_readlane pair, no LDS round trip.  hipcc adds no hazard padding inside asm
+// statements, so the two wait states a DPP read needs after a VALU write are in the string.
+template <int L>
+__device__ __forceinline__ void fmac_bcast(double &acc, double from_lane, double mult) {
+  asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+               : "+v"(acc)
+               : "v"(from_lane), "v"(mult), "n"(L));
+}
+template <int L>
+__device__ __forceinline__ double bcast16(double v) {
+  double r;
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+               : "=v"(r)
+               : "v"(v), "n"(L));
+  return r;
+}
+
+// rank-1 update of columns K..15 with pivot column J:  a[K] += A[K][J] * (-l_i)
+template <int J, int K>
+__device__ __forceinline__ void tile_elim(double (&a)[16], double negl) {
+  if constexpr (K < 16) {
+    fmac_bcast<K>(a[K], a[J], negl);
+    tile_elim<J, K + 1>(a, negl);
+  }
+}
+// unblocked LDL^T of the 16 x 16 tile whose row (lane & 15) is in a[0..15]
+template <int J>
+__device__ __forceinline__ void tile_factor(double (&a)[16], int l15, int cb, int nb, double &d_mine,
+                                            double &di_mine, int &bad_any) {
+  if constexpr (J < 16) {
+    const double d = bcast16<J>(a[J]);
+    const bool bad = (d == 0.0) || !(fabs(d) <= 1.79e308);
+    const double di = bad ? 0.0 : fast_recip(d);
+    bad_any |= (bad && (cb + J) < nb) ? 1 : 0;
+    if (l15 == J) {
+      d_mine = d;
+      di_mine = di;
+    }
+    const double l = a[J] * di;
+    tile_elim<J, J + 1>(a, -l);
+    a[J] = l;
+    tile_factor<J + 1>(a, l15, cb, nb, d_mine, di_mine, bad_any);
+  }
+}
+// substitution x L_bb^T = a_row for one row per lane; tl[c] of lane j holds L_bb[j][c]
+template <int T, int J>
+__device__ __forceinline__ void subst_inner(double (&x)[16], const double (&tl)[16], double negxt) {
+  if constexpr (J < 16) {
+    fmac_bcast<J>(x[J], tl[T], negxt);  // x[J] -= x[T] * L_bb[J][T]
+    subst_inner<T, J + 1>(x, tl, negxt);
+  }
+}
+template <int T>
+__device__ __forceinline__ void subst_rows(double (&x)[16], const double (&tl)[16]) {
+  if constexpr (T < 15) {
+    subst_inner<T, T + 1>(x, tl, -x[T]);
+    subst_rows<T + 1>(x, tl);
+  }
+}
+
 // ------------------------------------------------------------------ wide panel kernel
 // Same algorithm as panel_body, generalised to a PW-column panel (PW = 128: half as many
 // panel launches and two of three inner updates per outer block disappear) with OWN rows
@@ -611,32 +676,19 @@ __device__ __forceinline__ void panel_body2(unsigned char *smem, const int wg,
 
   for (int sb = 0; sb < CT; ++sb) {
     const int cb = sb * 16;
-    // ---- (a) 16 x 16 diagonal tile: wavefront 0, lane (l & 15) <-> row
+    // ---- (a) 16 x 16 diagonal tile: wavefront 0, lane (l & 15) <-> row (every 16-lane row
+    // of the wavefront holds the same tile, so row_newbcast works in all four)
+    double tl[16];  // the factored tile's rows, kept in registers for (b)
     if (wave == 0 && !(skip & 1)) {
-      double a[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) a[k] = M[LY::off(cb + l15, cb + k)];
+      for (int k = 0; k < 16; ++k) tl[k] = M[LY::off(cb + l15, cb + k)];
       double d_mine = 1.0, di_mine = 1.0;
       int bad_any = 0;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const double d = lane_bcast(a[j], j);
-        const bool bad = (d == 0.0) || !(fabs(d) <= 1.79e308);
-        const double di = bad ? 0.0 : fast_recip(d);
-        bad_any |= (bad && (cb + j) < nb) ? 1 : 0;
-        if (l15 == j) {
-          d_mine = d;
-          di_mine = di;
-        }
-        const double l = a[j] * di;
-#pragma unroll
-        for (int k = j + 1; k < 16; ++k) a[k] = fma(-l, lane_bcast(a[j], k), a[k]);
-        a[j] = l;
-      }
+      tile_factor<0>(tl, l15, cb, nb, d_mine, di_mine, bad_any);
       if (lane < 16) {
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-          if (k < lane) M[LY::off(cb + lane, cb + k)] = a[k];
+          if (k < lane) M[LY::off(cb + lane, cb + k)] = tl[k];
         M[LY::off(cb + lane, cb + lane)] = d_mine;
         dD[cb + lane] = d_mine;
         dI[cb + lane] = di_mine;
@@ -644,24 +696,28 @@ __device__ __forceinline__ void panel_body2(unsigned char *smem, const int wg,
       }
     }
     __syncthreads();
-    // ---- (b) rows below the tile: substitution, one lane per row
+    // ---- (b) rows below the tile: substitution, one lane per row; L_bb comes from the
+    // tile registers of the lane's own 16-lane row through row_newbcast (wavefront 0 still
+    // has them from (a); the others reload the factored tile from LDS)
     {
       const int row = cb + 16 + wave * 64 + lane;
-      if (row < R && !(skip & 2)) {
+      const bool wave_has_rows = (cb + 16 + wave * 64) < R;  // wave-uniform
+      if (wave_has_rows && !(skip & 2)) {
+        if (wave != 0) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) tl[k] = M[LY::off(cb + l15, cb + k)];
+        }
+        const int rowc = min(row, R - 1);  // lanes past the stack compute on a valid row
         double x[16];
-        const double *xr = &M[LY::off(row, cb)];
+        const double *xr = &M[LY::off(rowc, cb)];
 #pragma unroll
         for (int k = 0; k < 16; k += 2) {
           const double2_t v = *reinterpret_cast<const double2_t *>(xr + k);
           x[k] = v.x;
           x[k + 1] = v.y;
         }
-#pragma unroll
-        for (int t = 0; t < 15; ++t) {
-          const double xt = x[t];
-#pragma unroll
-          for (int j = t + 1; j < 16; ++j) x[j] = fma(-xt, M[LY::off(cb + j, cb + t)], x[j]);
-        }
+        subst_rows<0>(x, tl);
+        if (row < R) {
         double *xw = &M[LY::off(row, cb)];
 #pragma unroll
         for (int k = 0; k < 16; k += 2) {
@@ -685,6 +741,7 @@ __device__ __forceinline__ void panel_body2(unsigned char *smem, const int wg,
               st_f64x2(wp + k, w, coh);
             }
           }
+        }
         }
       }
     }
