@@ -73,8 +73,11 @@ __device__ __forceinline__ double fast_recip(double d) {
   double r = __builtin_amdgcn_rcp(d);
   double e = fma(-d, r, 1.0);
   r = fma(r, e, r);
+#ifndef PGF_RECIP_ONE_STEP
   e = fma(-d, r, 1.0);
-  return fma(r, e, r);
+  r = fma(r, e, r);
+#endif
+  return r;
 }
 
 // ------------------------------------------------------------------ fused panel kernel
