@@ -170,6 +170,36 @@ int pgf_profile_enable(pgf_handle h, int on);
 int pgf_profile_read(pgf_handle h, double *update_ms, int64_t *update_launches,
                      double *update_flops, double *factor_ms);
 
+/* ---- batched mode: many device-resident instances advanced by ONE launch sequence ---- */
+/* The reference's only parallelism is a process pool over independent instances
+ * (runners/runner.py:107-153); BASELINE configs[3] is 256 instances of (n=1024, m=256).
+ * A batch groups existing dense linear-quadratic handles of identical (n, m) on one
+ * device (each set up through pgf_set_bounds / pgf_qp_set_problem / pgf_qp_set_point);
+ * every kernel of the Newton step then runs over all instances at once (instance =
+ * blockIdx.z, reduced sizes read on the device: no host round trip inside a step).
+ * While a handle belongs to a batch, drive it only through the batch. */
+typedef struct pgf_batch_s *pgf_batch;
+int pgf_batch_create(const pgf_handle *handles, int count, pgf_batch *out);
+int pgf_batch_destroy(pgf_batch b);
+const char *pgf_batch_last_error(pgf_batch b);
+/* pgf_qp_advance_outer for every instance: (x^, y^) <- (x, y), new dt and rho */
+int pgf_batch_advance_outer(pgf_batch b, double dt, double rho);
+/* pgf_qp_update_active_set for every instance (SimplifiedNewtonMethod.__init__) */
+int pgf_batch_update_active_set(pgf_batch b, double tau);
+/* one NewtonMethod.step per instance (policy bits as pgf_qp_step); enqueue only */
+int pgf_batch_step_async(pgf_batch b, unsigned policy, double tau);
+/* wait; per instance: status (PGF_OK / PGF_SINGULAR), negative pivots of the factor in
+ * use, ||(dx, dy)||.  Any output may be NULL.  Returns PGF_OK even when single instances
+ * failed -- their status says so (the reference would reject only those steps). */
+int pgf_batch_sync(pgf_batch b, int *status, int *n_neg, double *diff);
+/* unscaled residual norms of all instances: host array and / or device array (the
+ * rank-local block of the RCCL all-gather) */
+int pgf_batch_residual_norms(pgf_batch b, double *norms_out, double *norms_out_dev);
+/* all points / masks, instance-major: x[count][n], y[count][m], mask[count][n] */
+int pgf_batch_get_points(pgf_batch b, double *x, double *y);
+int pgf_batch_get_masks(pgf_batch b, uint8_t *mask);
+int pgf_batch_stream(pgf_batch b, void **stream_out);
+
 /* ---- stand-alone dense linear solver (LinearSolver ABC) ------------------ */
 /* LinearSolver.__init__ factorises in the constructor
  * (linear_solver/linear_solver.py:18-21, lu_solver.py:9-17).  A: dense row-major N x N.

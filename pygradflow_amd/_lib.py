@@ -66,6 +66,17 @@ SIGNATURES = {
     "pgf_stream": (C.c_int, [_h, C.POINTER(C.c_void_p)]),
     "pgf_profile_enable": (C.c_int, [_h, C.c_int]),
     "pgf_profile_read": (C.c_int, [_h, _dp, C.POINTER(C.c_int64), _dp, _dp]),
+    "pgf_batch_create": (C.c_int, [C.POINTER(_h), C.c_int, C.POINTER(_h)]),
+    "pgf_batch_destroy": (C.c_int, [_h]),
+    "pgf_batch_last_error": (C.c_char_p, [_h]),
+    "pgf_batch_advance_outer": (C.c_int, [_h, C.c_double, C.c_double]),
+    "pgf_batch_update_active_set": (C.c_int, [_h, C.c_double]),
+    "pgf_batch_step_async": (C.c_int, [_h, C.c_uint, C.c_double]),
+    "pgf_batch_sync": (C.c_int, [_h, _ip, _ip, _dp]),
+    "pgf_batch_residual_norms": (C.c_int, [_h, _dp, C.c_void_p]),
+    "pgf_batch_get_points": (C.c_int, [_h, _dp, _dp]),
+    "pgf_batch_get_masks": (C.c_int, [_h, _u8p]),
+    "pgf_batch_stream": (C.c_int, [_h, C.POINTER(C.c_void_p)]),
     "pgf_ls_create_dense": (C.c_int, [C.c_int, _dp, C.c_int64, C.c_int, C.c_int, C.POINTER(_h)]),
     "pgf_ls_solve": (C.c_int, [_h, _dp, C.c_int, _dp]),
     "pgf_ls_num_neg": (C.c_int, [_h, _ip]),
@@ -136,11 +147,13 @@ def as_f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
-def check(rc, handle=None, what=""):
+def check(rc, handle=None, what="", batch=None):
     if rc == PGF_OK:
         return
     msg = ""
-    if handle is not None:
+    if batch is not None:
+        msg = load().pgf_batch_last_error(batch).decode(errors="replace")
+    elif handle is not None:
         msg = load().pgf_last_error(handle).decode(errors="replace")
     text = f"{what}: {msg}" if what else msg
     if rc in (PGF_SINGULAR, PGF_INERTIA):

@@ -60,40 +60,129 @@ def gather_residual_norms(local_norms, num_instances: int, group=None):
 class BatchedDeviceNewton:
     """This rank's shard of a batch of linear-quadratic instances, all resident in HBM.
 
-    ``make_problem(i)`` builds instance ``i``; ``step()`` advances every local instance by
-    one Newton step and returns the gathered residual norms of the whole batch.
+    ``make_problem(i)`` builds instance ``i`` (all of one shape).  The shard's instances are
+    grouped into ONE device batch (``pgf_batch_*``): every kernel of the Newton step runs
+    over all local instances at once, with no host round trip inside a step.  ``step()``
+    advances every local instance by one Newton step and returns the gathered residual
+    norms of the whole batch (one all-gather, nothing else crosses ranks).
+    ``sequential=True`` drives the instances one after another through their own handles
+    instead (the same kernels without the batch dimension; kept as the cross-check).
     """
 
     def __init__(self, make_problem, num_instances, newton_type, dt, rho, device=0, rank=0,
-                 world=1, group=None):
+                 world=1, group=None, tau=None, sequential=False):
+        import ctypes as C
+        import math
+
         import torch
 
-        from .newton import DeviceNewton
+        from . import _lib
+        from .newton import _POLICY_BITS, DeviceNewton
+        from .params import enum_name
 
         self.num_instances = num_instances
         self.rank, self.world, self.group = rank, world, group
         self.lo, self.hi = shard_range(num_instances, world, rank)
+        self.count = self.hi - self.lo
+        self.kind = enum_name(newton_type) if not isinstance(newton_type, str) else newton_type
+        self.policy = _POLICY_BITS[self.kind]
+        self.tau = math.nan if tau is None else float(tau)
+        self.dt, self.rho = float(dt), float(rho)
+        self.sequential = bool(sequential)
         self.solvers = []
         for i in range(self.lo, self.hi):
             prob = make_problem(i)
             x0, y0 = np.zeros(prob.num_vars), np.zeros(prob.num_cons)
-            self.solvers.append(DeviceNewton(prob, newton_type, x0, y0, dt, rho, device=device))
+            self.solvers.append(DeviceNewton(prob, newton_type, x0, y0, dt, rho, tau=tau,
+                                             device=device))
         self._torch = torch
+        self._lib, self._C = _lib, C
         self.device = torch.device("cuda", device)
-        self.norms = torch.zeros(max(1, self.hi - self.lo), dtype=torch.float64, device=self.device)
+        self.norms = torch.zeros(max(1, self.count), dtype=torch.float64, device=self.device)
+        self._b = None
+        if self.count and not self.sequential:
+            shapes = {(s.n, s.m, s.sparse) for s in self.solvers}
+            if len(shapes) != 1 or next(iter(shapes))[2]:
+                raise ValueError("a device batch needs dense instances of one (n, m)")
+            self.n, self.m = self.solvers[0].n, self.solvers[0].m
+            lib = _lib.load()
+            arr = (C.c_void_p * self.count)(*[s._hd.h for s in self.solvers])
+            b = C.c_void_p()
+            rc = lib.pgf_batch_create(arr, self.count, C.byref(b))
+            _lib.check(rc, self.solvers[0]._hd.h, "pgf_batch_create")
+            self._b = b
+            self._begin_outer()
 
-    def advance_outer(self):
-        for s in self.solvers:
-            s.advance_outer()
+    def _begin_outer(self):
+        lib, b = self._lib.load(), self._b
+        self._lib.check(lib.pgf_batch_advance_outer(b, self.dt, self.rho), batch=b,
+                        what="pgf_batch_advance_outer")
+        if self.kind == "Simplified":
+            self._lib.check(lib.pgf_batch_update_active_set(b, self.tau), batch=b,
+                            what="pgf_batch_update_active_set")
+
+    def advance_outer(self, dt=None, rho=None):
+        self.dt = self.dt if dt is None else float(dt)
+        self.rho = self.rho if rho is None else float(rho)
+        if self._b is None:
+            for s in self.solvers:
+                s.advance_outer(self.dt, self.rho)
+        else:
+            self._begin_outer()
+
+    def step_local(self):
+        """One Newton step of every local instance; returns (status, n_neg, diff) arrays.
+        The norms of the new points are left in ``self.norms`` (device)."""
+        C = self._C
+        cnt = self.count
+        status = np.zeros(cnt, dtype=np.int32)
+        n_neg = np.zeros(cnt, dtype=np.int32)
+        diff = np.zeros(cnt)
+        if cnt == 0:
+            return status, n_neg, diff
+        if self._b is None:
+            base = self.norms.data_ptr()
+            for k, s in enumerate(self.solvers):
+                diff[k], n_neg[k] = s.step()
+                s.residual_norm(base + 8 * k)
+            return status, n_neg, diff
+        lib, b = self._lib.load(), self._b
+        self._lib.check(lib.pgf_batch_step_async(b, self.policy, self.tau), batch=b,
+                        what="pgf_batch_step_async")
+        ip = C.POINTER(C.c_int)
+        self._lib.check(lib.pgf_batch_sync(b, status.ctypes.data_as(ip), n_neg.ctypes.data_as(ip),
+                                           self._lib.dptr(diff)), batch=b, what="pgf_batch_sync")
+        self._lib.check(lib.pgf_batch_residual_norms(b, None, self.norms.data_ptr()), batch=b,
+                        what="pgf_batch_residual_norms")
+        return status, n_neg, diff
 
     def step(self):
-        base = self.norms.data_ptr()
-        for k, s in enumerate(self.solvers):
-            s.step()
-            s.residual_norm(base + 8 * k)
-        return gather_residual_norms(self.norms[: self.hi - self.lo], self.num_instances, self.group)
+        self.step_local()
+        return gather_residual_norms(self.norms[: self.count], self.num_instances, self.group)
+
+    def points(self):
+        """(x[count][n], y[count][m]) of the local instances (host copies)."""
+        if self._b is None:
+            pts = [s.point() for s in self.solvers]
+            return np.array([p[0] for p in pts]), np.array([p[1] for p in pts])
+        x = np.empty((self.count, self.n))
+        y = np.empty((self.count, self.m))
+        self._lib.check(self._lib.load().pgf_batch_get_points(self._b, self._lib.dptr(x),
+                                                               self._lib.dptr(y)), batch=self._b)
+        return x, y
+
+    def masks(self):
+        if self._b is None:
+            return np.array([s.mask() for s in self.solvers])
+        mk = np.empty((self.count, self.n), dtype=np.bool_)
+        self._lib.check(self._lib.load().pgf_batch_get_masks(self._b, self._lib.u8ptr(mk)),
+                        batch=self._b)
+        return mk
 
     def close(self):
+        if self._b is not None:
+            self._lib.load().pgf_batch_destroy(self._b)
+            self._b = None
         for s in self.solvers:
             s.close()
         self.solvers = []

@@ -867,6 +867,315 @@ int pgf_qp_residual_norm(pgf_handle h, double *norm_out, double *norm_out_dev) {
   return PGF_OK;
 }
 
+// ---------------------------------------------------------------- batched mode
+struct pgf_batch_s {
+  std::vector<pgf_handle> hs;
+  int B = 0, n = 0, m = 0, device = 0, OB = 256;
+  hipStream_t stream = nullptr;
+  BInst *tab = nullptr;
+  int *ctl = nullptr, *flags_out = nullptr, *h_flags = nullptr;
+  double *diff_out = nullptr, *norm_out = nullptr, *h_diff = nullptr, *h_norm = nullptr;
+  BatchScalars sc{};
+  bool outer_set = false, eval_fresh = false, step_pending = false, have_mask = false;
+  bool all_factored = false;
+  std::string err = "";
+};
+
+static int bfail(pgf_batch b, int code, const char *msg) {
+  if (b) b->err = msg;
+  return code;
+}
+
+#define BHIPCHK(b, expr)                                                 \
+  do {                                                                   \
+    hipError_t e_ = (expr);                                              \
+    if (e_ != hipSuccess) {                                              \
+      (b)->err = std::string(#expr) + ": " + hipGetErrorString(e_);      \
+      return PGF_HIP_ERROR + (int)e_;                                    \
+    }                                                                    \
+  } while (0)
+
+const char *pgf_batch_last_error(pgf_batch b) { return b ? b->err.c_str() : k_no_handle; }
+
+int pgf_batch_create(const pgf_handle *handles, int count, pgf_batch *out) {
+  if (!out || !handles || count <= 0 || count > 65535) return PGF_INVALID;
+  const pgf_handle h0 = handles[0];
+  if (!h0) return PGF_INVALID;
+  for (int i = 0; i < count; ++i) {
+    const pgf_handle h = handles[i];
+    if (!h) return PGF_INVALID;
+    if (h->n != h0->n || h->m != h0->m || h->device != h0->device)
+      return fail(h, PGF_INVALID, "batch: instances must share n, m and the device");
+    if (h->sparse) return fail(h, PGF_INVALID, "batch: dense handles only");
+    if (!h->qp_mode || !h->bounds_set || !h->point_set)
+      return fail(h, PGF_NOT_READY, "batch: pgf_set_bounds, pgf_qp_set_problem, pgf_qp_set_point first");
+    if (h->step_pending) return fail(h, PGF_NOT_READY, "batch: a step is pending");
+  }
+  pgf_batch b = new (std::nothrow) pgf_batch_s();
+  if (!b) return PGF_INVALID;
+  b->hs.assign(handles, handles + count);
+  b->B = count;
+  b->n = h0->n;
+  b->m = h0->m;
+  b->device = h0->device;
+  b->OB = h0->fac.OB;
+  b->sc.n = b->n;
+  b->sc.m = b->m;
+  (void)hipSetDevice(b->device);
+  hipError_t e;
+  std::vector<BInst> tab(count);
+  if ((e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipMalloc((void **)&b->tab, count * sizeof(BInst))) != hipSuccess ||
+      (e = hipMalloc((void **)&b->ctl, (size_t)count * 4 * sizeof(int))) != hipSuccess ||
+      (e = hipMalloc((void **)&b->flags_out, (size_t)count * 2 * sizeof(int))) != hipSuccess ||
+      (e = hipMalloc((void **)&b->diff_out, count * sizeof(double))) != hipSuccess ||
+      (e = hipMalloc((void **)&b->norm_out, count * sizeof(double))) != hipSuccess ||
+      (e = hipHostMalloc((void **)&b->h_flags, (size_t)count * 2 * sizeof(int))) != hipSuccess ||
+      (e = hipHostMalloc((void **)&b->h_diff, count * sizeof(double))) != hipSuccess ||
+      (e = hipHostMalloc((void **)&b->h_norm, count * sizeof(double))) != hipSuccess) {
+    pgf_batch_destroy(b);
+    return PGF_HIP_ERROR + (int)e;
+  }
+  for (int i = 0; i < count; ++i) {
+    const pgf_handle h = handles[i];
+    (void)hipStreamSynchronize(h->stream);
+    BInst &t = tab[i];
+    t.H = h->H;
+    t.J = h->J;
+    t.ldh = h->ldh;
+    t.ldj = h->ldj;
+    t.lb = h->lb;
+    t.ub = h->ub;
+    t.q = h->q;
+    t.b = h->b;
+    t.slb = h->slb;
+    t.sub = h->sub;
+    t.xhat = h->xhat;
+    t.yhat = h->yhat;
+    t.x = h->x;
+    t.y = h->y;
+    t.xn = h->xn;
+    t.yn = h->yn;
+    t.g = h->g;
+    t.c = h->c;
+    t.F = h->F;
+    t.b0full = h->b0full;
+    t.rhs = h->rhs;
+    t.sol = h->sol;
+    t.dx = h->dx;
+    t.dy = h->dy;
+    t.w = h->w;
+    t.tmpn = h->tmpn;
+    t.partial = h->partial;
+    t.red = h->red;
+    t.mask = h->mask;
+    t.mask_new = h->mask_new;
+    t.idxI = h->idxI;
+    t.idxA = h->idxA;
+    t.pos = h->pos;
+    t.counts = h->counts;
+    t.ctl = b->ctl + 4 * i;
+    t.K = h->fac.K;
+    t.ldk = h->fac.ldk;
+    t.W = h->fac.W;
+    t.wstride = (int64_t)h->fac.wstride;
+    t.dvec = h->fac.dvec;
+    t.dinv = h->fac.dinv;
+    t.zwork = h->fac.zwork;
+    t.Linv = h->fac.Linv;
+    t.LinvT = h->fac.LinvT;
+    t.flags = h->fac.flags;
+    // the batch owns the device-side state of the handle from here on
+    h->mask_set = false;
+    h->eval_fresh = false;
+    invalidate_factor(h);
+  }
+  if ((e = hipMemcpy(b->tab, tab.data(), count * sizeof(BInst), hipMemcpyHostToDevice)) !=
+          hipSuccess ||
+      (e = hipMemset(b->ctl, 0, (size_t)count * 4 * sizeof(int))) != hipSuccess ||
+      (e = hipMemset(b->flags_out, 0, (size_t)count * 2 * sizeof(int))) != hipSuccess) {
+    pgf_batch_destroy(b);
+    return PGF_HIP_ERROR + (int)e;
+  }
+  *out = b;
+  return PGF_OK;
+}
+
+int pgf_batch_destroy(pgf_batch b) {
+  if (!b) return PGF_OK;
+  (void)hipSetDevice(b->device);
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  for (void *p : {(void *)b->tab, (void *)b->ctl, (void *)b->flags_out, (void *)b->diff_out,
+                  (void *)b->norm_out})
+    if (p) (void)hipFree(p);
+  for (void *p : {(void *)b->h_flags, (void *)b->h_diff, (void *)b->h_norm})
+    if (p) (void)hipHostFree(p);
+  if (b->stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+  return PGF_OK;
+}
+
+int pgf_batch_stream(pgf_batch b, void **stream_out) {
+  if (!b || !stream_out) return PGF_INVALID;
+  *stream_out = (void *)b->stream;
+  return PGF_OK;
+}
+
+int pgf_batch_advance_outer(pgf_batch b, double dt, double rho) {
+  if (!b) return PGF_INVALID;
+  if (!(dt > 0.0) || !(rho > 0.0)) return bfail(b, PGF_INVALID, "dt and rho must be positive");
+  if (b->step_pending) return bfail(b, PGF_NOT_READY, "pgf_batch_sync the previous step first");
+  (void)hipSetDevice(b->device);
+  if (rho != b->sc.rho) b->eval_fresh = false;  // g depends on rho
+  b->sc.dt = dt;
+  b->sc.lamb = 1.0 / dt;
+  b->sc.rho = rho;
+  b->sc.fact = 1.0 / (1.0 + b->sc.lamb * rho);
+  b->sc.delta = b->sc.lamb / (1.0 + b->sc.lamb * rho);
+  batch_launch_advance(b->stream, b->tab, b->B, b->sc);
+  for (pgf_handle h : b->hs) {  // keep the handles' host-side view consistent
+    h->dt = dt;
+    h->lamb = b->sc.lamb;
+    h->rho = rho;
+    h->fact = b->sc.fact;
+    h->delta = b->sc.delta;
+    h->outer_set = true;
+  }
+  b->outer_set = true;
+  b->have_mask = false;
+  b->all_factored = false;
+  BHIPCHK(b, hipGetLastError());
+  return PGF_OK;
+}
+
+static void batch_eval(pgf_batch b) {
+  if (b->eval_fresh) return;
+  batch_launch_eval(b->stream, b->tab, b->B, b->sc, PGF_GEMVT_PARTS);
+  b->eval_fresh = true;
+}
+
+static void batch_tau(pgf_batch b, double tau, int *use_tau, double *f_x, double *f_x0,
+                      double *f_d) {
+  // same factors as tau_factors() (implicit_func.py:237-244)
+  pgf_handle h = b->hs[0];
+  tau_factors(h, tau, use_tau, f_x, f_x0, f_d);
+}
+
+int pgf_batch_update_active_set(pgf_batch b, double tau) {
+  if (!b) return PGF_INVALID;
+  if (!b->outer_set) return bfail(b, PGF_NOT_READY, "pgf_batch_advance_outer first");
+  if (b->step_pending) return bfail(b, PGF_NOT_READY, "pgf_batch_sync the previous step first");
+  (void)hipSetDevice(b->device);
+  batch_eval(b);
+  int use_tau;
+  double f_x, f_x0, f_d;
+  batch_tau(b, tau, &use_tau, &f_x, &f_x0, &f_d);
+  batch_launch_mask(b->stream, b->tab, b->B, b->sc, 1, use_tau, f_x, f_x0, f_d);
+  b->have_mask = true;
+  b->all_factored = false;
+  BHIPCHK(b, hipGetLastError());
+  return PGF_OK;
+}
+
+int pgf_batch_step_async(pgf_batch b, unsigned policy, double tau) {
+  if (!b) return PGF_INVALID;
+  if (!b->outer_set) return bfail(b, PGF_NOT_READY, "pgf_batch_advance_outer first");
+  if (b->step_pending) return bfail(b, PGF_NOT_READY, "pgf_batch_sync the previous step first");
+  (void)hipSetDevice(b->device);
+  const bool recompute = (policy & PGF_STEP_RECOMPUTE_MASK) != 0;
+  const bool force = (policy & PGF_STEP_REFACTOR) != 0;
+  if (!recompute && !b->have_mask)
+    return bfail(b, PGF_NOT_READY, "no active set: pgf_batch_update_active_set first");
+  if (!recompute && force)
+    return bfail(b, PGF_INVALID, "batch: PGF_STEP_REFACTOR needs PGF_STEP_RECOMPUTE_MASK");
+  batch_eval(b);
+  int use_tau = 0;
+  double f_x = 0, f_x0 = 0, f_d = 0;
+  if (recompute) batch_tau(b, tau, &use_tau, &f_x, &f_x0, &f_d);
+  batch_launch_mask(b->stream, b->tab, b->B, b->sc, recompute ? (force ? 2 : 1) : 0, use_tau, f_x,
+                    f_x0, f_d);
+  b->have_mask = true;
+  batch_launch_rhs_assemble(b->stream, b->tab, b->B, b->sc);
+  const int Nmax = b->n + b->m;
+  // kernels of instances whose factor is still valid return at once (ctl[0] == 0); when the
+  // host knows that every instance refactorises (Full) or none does, skip the other half
+  const bool none_factor = !recompute && b->all_factored;
+  if (!none_factor) ldlt_batch_factor_async(b->stream, b->tab, b->B, Nmax, b->m, b->OB);
+  ldlt_batch_solve_async(b->stream, b->tab, b->B, Nmax, b->m, !force);
+  batch_launch_step_update(b->stream, b->tab, b->B, b->sc, b->diff_out, b->flags_out);
+  b->eval_fresh = false;
+  BHIPCHK(b, hipMemcpyAsync(b->h_diff, b->diff_out, b->B * sizeof(double), hipMemcpyDeviceToHost,
+                            b->stream));
+  BHIPCHK(b, hipMemcpyAsync(b->h_flags, b->flags_out, (size_t)b->B * 2 * sizeof(int),
+                            hipMemcpyDeviceToHost, b->stream));
+  b->step_pending = true;
+  return PGF_OK;
+}
+
+int pgf_batch_sync(pgf_batch b, int *status, int *n_neg, double *diff) {
+  if (!b) return PGF_INVALID;
+  if (!b->step_pending) return bfail(b, PGF_NOT_READY, "no step pending");
+  b->step_pending = false;
+  (void)hipSetDevice(b->device);
+  BHIPCHK(b, hipStreamSynchronize(b->stream));
+  bool all_ok = true;
+  for (int i = 0; i < b->B; ++i) {
+    const bool bad = b->h_flags[2 * i] != 0;
+    all_ok = all_ok && !bad;
+    if (status) status[i] = bad ? PGF_SINGULAR : PGF_OK;
+    if (n_neg) n_neg[i] = b->h_flags[2 * i + 1];
+    if (diff) diff[i] = b->h_diff[i];
+  }
+  b->all_factored = all_ok;
+  return PGF_OK;
+}
+
+int pgf_batch_residual_norms(pgf_batch b, double *norms_out, double *norms_out_dev) {
+  if (!b) return PGF_INVALID;
+  if (!b->outer_set) return bfail(b, PGF_NOT_READY, "pgf_batch_advance_outer first");
+  if (b->step_pending) return bfail(b, PGF_NOT_READY, "pgf_batch_sync the previous step first");
+  (void)hipSetDevice(b->device);
+  batch_eval(b);
+  batch_launch_res_norm(b->stream, b->tab, b->B, b->sc, b->norm_out);
+  if (norms_out_dev)
+    BHIPCHK(b, hipMemcpyAsync(norms_out_dev, b->norm_out, b->B * sizeof(double),
+                              hipMemcpyDeviceToDevice, b->stream));
+  BHIPCHK(b, hipMemcpyAsync(b->h_norm, b->norm_out, b->B * sizeof(double), hipMemcpyDeviceToHost,
+                            b->stream));
+  BHIPCHK(b, hipStreamSynchronize(b->stream));
+  if (norms_out) std::memcpy(norms_out, b->h_norm, b->B * sizeof(double));
+  return PGF_OK;
+}
+
+int pgf_batch_get_points(pgf_batch b, double *x, double *y) {
+  if (!b) return PGF_INVALID;
+  if (b->step_pending) return bfail(b, PGF_NOT_READY, "pgf_batch_sync the previous step first");
+  (void)hipSetDevice(b->device);
+  for (int i = 0; i < b->B; ++i) {
+    if (x && b->n)
+      BHIPCHK(b, hipMemcpyAsync(x + (size_t)i * b->n, b->hs[i]->x, b->n * sizeof(double),
+                                hipMemcpyDeviceToHost, b->stream));
+    if (y && b->m)
+      BHIPCHK(b, hipMemcpyAsync(y + (size_t)i * b->m, b->hs[i]->y, b->m * sizeof(double),
+                                hipMemcpyDeviceToHost, b->stream));
+  }
+  BHIPCHK(b, hipStreamSynchronize(b->stream));
+  return PGF_OK;
+}
+
+int pgf_batch_get_masks(pgf_batch b, uint8_t *mask) {
+  if (!b || !mask) return PGF_INVALID;
+  if (!b->have_mask) return bfail(b, PGF_NOT_READY, "no active set");
+  if (b->step_pending) return bfail(b, PGF_NOT_READY, "pgf_batch_sync the previous step first");
+  (void)hipSetDevice(b->device);
+  for (int i = 0; i < b->B; ++i)
+    if (b->n)
+      BHIPCHK(b, hipMemcpyAsync(mask + (size_t)i * b->n, b->hs[i]->mask, b->n,
+                                hipMemcpyDeviceToHost, b->stream));
+  BHIPCHK(b, hipStreamSynchronize(b->stream));
+  return PGF_OK;
+}
+
 int pgf_stream(pgf_handle h, void **stream_out) {
   if (!h || !stream_out) return PGF_INVALID;
   *stream_out = (void *)h->stream;

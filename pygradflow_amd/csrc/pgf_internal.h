@@ -58,6 +58,49 @@ hipError_t ldlt_solve_async(DenseLdlt &f, const double *rhs, double *sol);
 // backward half only: sol <- L^{-T} w, w already equals D^{-1} L^{-1} rhs (row N trick)
 hipError_t ldlt_backsolve_async(DenseLdlt &f, const double *w, double *sol);
 
+// ---- batched mode ----------------------------------------------------------
+// One entry per instance of a batch (all instances share n, m): the device addresses of an
+// ordinary solver handle.  Batched kernels pick their instance with blockIdx.z and read the
+// instance's own reduced size N = counts[0] + m on the device, so a whole batched Newton
+// step is enqueued without a host round trip.  ctl: [0] factor this step, [1] factor
+// valid, [2] mask valid.
+struct BInst {
+  const double *H, *J;
+  int64_t ldh, ldj;
+  const double *lb, *ub, *q, *b;
+  double *slb, *sub, *xhat, *yhat, *x, *y, *xn, *yn, *g, *c, *F, *b0full, *rhs, *sol, *dx, *dy;
+  double *w, *tmpn, *partial, *red;
+  uint8_t *mask, *mask_new;
+  int *idxI, *idxA, *pos, *counts, *ctl;
+  double *K;
+  int64_t ldk;
+  double *W;
+  int64_t wstride;
+  double *dvec, *dinv, *zwork, *Linv, *LinvT;
+  int *flags;
+};
+
+struct BatchScalars {
+  int n, m;
+  double dt, lamb, rho, fact, delta;
+};
+
+// pgf_kernels.hip
+void batch_launch_advance(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc);
+void batch_launch_eval(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc, int nparts);
+// mode 1: adopt mask_new where it differs (or no mask yet); 2: always adopt; 0: keep
+void batch_launch_mask(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc, int mode,
+                       int use_tau, double f_x, double f_x0, double f_d);
+void batch_launch_rhs_assemble(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc);
+void batch_launch_step_update(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc,
+                              double *diff_out, int *flags_out);
+void batch_launch_res_norm(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc,
+                           double *norm_out);
+// pgf_ldlt.hip
+void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m, int OB);
+void ldlt_batch_solve_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m,
+                            bool any_unfactored_solve);
+
 // ---- elementwise / assembly launches (pgf_kernels.hip) --------------------
 struct StepDev;  // opaque here
 

@@ -5,10 +5,12 @@
 // scipy's anyway and is covered by the 1e-10 iterate tolerance).
 #include "pgf_kernels.h"
 
+#include "pgf_internal.h"
+
 #define ACTIVE_EPS 1e-8  // reference implicit_func.py:44
 
 // ---------------------------------------------------------------- bounds (a2)
-__global__ void k_scale_bounds(int n, double lamb, const double *__restrict__ lb,
+__device__ __forceinline__ void b_scale_bounds(int n, double lamb, const double *__restrict__ lb,
                                const double *__restrict__ ub, double *__restrict__ slb,
                                double *__restrict__ sub) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -21,7 +23,7 @@ __global__ void k_scale_bounds(int n, double lamb, const double *__restrict__ lb
 // ---------------------------------------------------------------- p and mask (a3, a4)
 // tau form: (f_x * x + f_x0 * x_hat) - f_d * g, evaluated left to right as numpy does
 // (implicit_func.py:237-244); plain form: lamb * x_hat - g (:246).
-__global__ void k_active_set(int n, int use_tau, double lamb, double f_x, double f_x0, double f_d,
+__device__ __forceinline__ void b_active_set(int n, int use_tau, double lamb, double f_x, double f_x0, double f_d,
                              const double *__restrict__ xhat, const double *__restrict__ x,
                              const double *__restrict__ g, const double *__restrict__ slb,
                              const double *__restrict__ sub, uint8_t *__restrict__ mask) {
@@ -45,7 +47,7 @@ __global__ void k_active_set(int n, int use_tau, double lamb, double f_x, double
 // One workgroup of 1024 lanes walks the mask in chunks; wavefront ballots + a scan of the
 // 16 wave totals give stable (ascending) index lists of the inactive and active sets.
 // pos[j] = rank of j inside its own list.
-__global__ __launch_bounds__(1024) void k_compact(int n, const uint8_t *__restrict__ mask,
+__device__ __forceinline__ void b_compact(int n, const uint8_t *__restrict__ mask,
                                                   int *__restrict__ idxI, int *__restrict__ idxA,
                                                   int *__restrict__ pos, int *__restrict__ counts) {
   __shared__ int wtot[16];
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(1024) void k_compact(int n, const uint8_t *__restri
 // ---------------------------------------------------------------- residual (a5, a6)
 // F = [lamb x - P(p) ; -(lamb y - (lamb y_hat + c))], P clips only masked entries
 // (np.clip == min(max(p, lo), hi)).  Also emits b0full = mask ? dt * F_x : 0 (a8).
-__global__ void k_residual(int n, int m, double lamb, double dt, const double *__restrict__ xhat,
+__device__ __forceinline__ void b_residual(int n, int m, double lamb, double dt, const double *__restrict__ xhat,
                            const double *__restrict__ yhat, const double *__restrict__ x,
                            const double *__restrict__ y, const double *__restrict__ g,
                            const double *__restrict__ c, const double *__restrict__ slb,
@@ -143,7 +145,7 @@ __device__ __forceinline__ double row_dot(const double *__restrict__ row,
 //   i >= nI : rhs[i] = fact * F[n + r]    - J[r, :]    . b0full      (r = i - nI)
 // b0full is zero on the inactive set, so the full-row dot equals the reference's
 // H_lamb[I, A] b0 / J[:, A] b0 (symmetric_step_solver.py:87-91); skipped when |A| = 0.
-__global__ __launch_bounds__(256) void k_reduced_rhs(int n, int m, int nI, int nA, double fact,
+__device__ __forceinline__ void b_reduced_rhs(int n, int m, int nI, int nA, double fact,
                                                      const double *__restrict__ F,
                                                      const int *__restrict__ idxI,
                                                      const double *__restrict__ H, int64_t ldh,
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256) void k_reduced_rhs(int n, int m, int nI, int n
 // Lower triangle of K = [[H[I,I] + lamb I, .],[J[:,I], -delta I]] gathered from the
 // device-resident H, J.  blockIdx.y = row of K, lanes run along columns (coalesced
 // stores; loads coalesced whenever I is contiguous).
-__global__ __launch_bounds__(256) void k_assemble_kkt(double *__restrict__ K, int64_t ldk,
+__device__ __forceinline__ void b_assemble_kkt(double *__restrict__ K, int64_t ldk,
                                                       const double *__restrict__ H, int64_t ldh,
                                                       const double *__restrict__ J, int64_t ldj,
                                                       const int *__restrict__ idxI, int nI, int m,
@@ -195,18 +197,18 @@ __global__ __launch_bounds__(256) void k_assemble_kkt(double *__restrict__ K, in
   K[(int64_t)i * ldk + j] = v;
 }
 
-__global__ void k_copy(double *__restrict__ dst, const double *__restrict__ src, int n) {
+__device__ __forceinline__ void b_copy(double *__restrict__ dst, const double *__restrict__ src, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i];
 }
 
-__global__ void k_copy_u8(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int n) {
+__device__ __forceinline__ void b_copy_u8(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i];
 }
 
 // count positions where two masks differ (ActiveSet policy, newton.py:210)
-__global__ void k_mask_diff(int n, const uint8_t *__restrict__ a, const uint8_t *__restrict__ b,
+__device__ __forceinline__ void b_mask_diff(int n, const uint8_t *__restrict__ a, const uint8_t *__restrict__ b,
                             int *__restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool d = (i < n) && (a[i] != b[i]);
@@ -218,7 +220,7 @@ __global__ void k_mask_diff(int n, const uint8_t *__restrict__ a, const uint8_t 
 // dx[I] = s[:nI], dx[A] = b0;  dy = fact * (s[nI:] - rho * b2)
 // xn = clip(x - dx, lb, ub) with dx rewritten where clipped; yn = y - dy
 // per-block partial sums of dx^2 + dy^2 in fixed order -> red[blockIdx.x]
-__global__ __launch_bounds__(256) void k_step_update(
+__device__ __forceinline__ void b_step_update(
     int n, int m, int nI, double fact, double rho, const double *__restrict__ x,
     const double *__restrict__ y, const double *__restrict__ lb, const double *__restrict__ ub,
     const uint8_t *__restrict__ mask, const int *__restrict__ pos,
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void k_step_update(
 }
 
 // out[0] = sqrt(sum red[0..cnt)) (or the plain sum when take_sqrt == 0), fixed order
-__global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__ red, int cnt,
+__device__ __forceinline__ void b_final_reduce(const double *__restrict__ red, int cnt,
                                                       double *__restrict__ out, int take_sqrt) {
   __shared__ double part[4];
   double s = 0.0;
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__
 
 // ---------------------------------------------------------------- linear-quadratic evaluation
 // out[r] = M[r, :] . v + sgn * add[r]     (c = A x - b ;  g = Q x + (q + A'(rho c + y)))
-__global__ __launch_bounds__(256) void k_gemv_rows(int rows, int cols,
+__device__ __forceinline__ void b_gemv_rows(int rows, int cols,
                                                    const double *__restrict__ M, int64_t ld,
                                                    const double *__restrict__ v,
                                                    const double *__restrict__ add, double sgn,
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void k_gemv_rows(int rows, int cols,
 }
 
 // partial[rb][j] = sum_{r in chunk rb} M[r][j] * w[r]   (transposed product, fixed order)
-__global__ __launch_bounds__(256) void k_gemvT_partial(int rows, int cols,
+__device__ __forceinline__ void b_gemvT_partial(int rows, int cols,
                                                        const double *__restrict__ M, int64_t ld,
                                                        const double *__restrict__ w, int chunk,
                                                        double *__restrict__ partial) {
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(256) void k_gemvT_partial(int rows, int cols,
 }
 
 // out[j] = base[j] + sum_rb partial[rb][j]
-__global__ void k_sum_partials(int cols, int nparts, const double *__restrict__ partial,
+__device__ __forceinline__ void b_sum_partials(int cols, int nparts, const double *__restrict__ partial,
                                const double *__restrict__ base, double *__restrict__ out) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= cols) return;
@@ -312,7 +314,7 @@ __global__ void k_sum_partials(int cols, int nparts, const double *__restrict__ 
 }
 
 // w = rho * c + y
-__global__ void k_mult_vec(int m, double rho, const double *__restrict__ c,
+__device__ __forceinline__ void b_mult_vec(int m, double rho, const double *__restrict__ c,
                            const double *__restrict__ y, double *__restrict__ w) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < m) w[i] = rho * c[i] + y[i];
@@ -320,7 +322,7 @@ __global__ void k_mult_vec(int m, double rho, const double *__restrict__ c,
 
 // squared entries of the UNSCALED residual with its own mask (ImplicitFunc.value_at,
 // implicit_func.py:131-161): per-block partial sums -> red
-__global__ __launch_bounds__(256) void k_unscaled_res_sq(
+__device__ __forceinline__ void b_unscaled_res_sq(
     int n, int m, double dt, const double *__restrict__ xhat, const double *__restrict__ yhat,
     const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ g,
     const double *__restrict__ c, const double *__restrict__ lb, const double *__restrict__ ub,
@@ -343,6 +345,71 @@ __global__ __launch_bounds__(256) void k_unscaled_res_sq(
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sq;
   __syncthreads();
   if (threadIdx.x == 0) red[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// ---------------------------------------------------------------- single-instance kernels
+__global__ void k_scale_bounds(int n, double lamb, const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ slb, double *__restrict__ sub) {
+  b_scale_bounds(n, lamb, lb, ub, slb, sub);
+}
+
+__global__ void k_active_set(int n, int use_tau, double lamb, double f_x, double f_x0, double f_d, const double *__restrict__ xhat, const double *__restrict__ x, const double *__restrict__ g, const double *__restrict__ slb, const double *__restrict__ sub, uint8_t *__restrict__ mask) {
+  b_active_set(n, use_tau, lamb, f_x, f_x0, f_d, xhat, x, g, slb, sub, mask);
+}
+
+__global__ __launch_bounds__(1024) void k_compact(int n, const uint8_t *__restrict__ mask, int *__restrict__ idxI, int *__restrict__ idxA, int *__restrict__ pos, int *__restrict__ counts) {
+  b_compact(n, mask, idxI, idxA, pos, counts);
+}
+
+__global__ void k_residual(int n, int m, double lamb, double dt, const double *__restrict__ xhat, const double *__restrict__ yhat, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ g, const double *__restrict__ c, const double *__restrict__ slb, const double *__restrict__ sub, const uint8_t *__restrict__ mask, double *__restrict__ F, double *__restrict__ b0full) {
+  b_residual(n, m, lamb, dt, xhat, yhat, x, y, g, c, slb, sub, mask, F, b0full);
+}
+
+__global__ __launch_bounds__(256) void k_reduced_rhs(int n, int m, int nI, int nA, double fact, const double *__restrict__ F, const int *__restrict__ idxI, const double *__restrict__ H, int64_t ldh, const double *__restrict__ J, int64_t ldj, const double *__restrict__ b0full, double *__restrict__ rhs) {
+  b_reduced_rhs(n, m, nI, nA, fact, F, idxI, H, ldh, J, ldj, b0full, rhs);
+}
+
+__global__ __launch_bounds__(256) void k_assemble_kkt(double *__restrict__ K, int64_t ldk, const double *__restrict__ H, int64_t ldh, const double *__restrict__ J, int64_t ldj, const int *__restrict__ idxI, int nI, int m, double lamb, double delta) {
+  b_assemble_kkt(K, ldk, H, ldh, J, ldj, idxI, nI, m, lamb, delta);
+}
+
+__global__ void k_copy(double *__restrict__ dst, const double *__restrict__ src, int n) {
+  b_copy(dst, src, n);
+}
+
+__global__ void k_copy_u8(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int n) {
+  b_copy_u8(dst, src, n);
+}
+
+__global__ void k_mask_diff(int n, const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, int *__restrict__ out) {
+  b_mask_diff(n, a, b, out);
+}
+
+__global__ __launch_bounds__(256) void k_step_update(int n, int m, int nI, double fact, double rho, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ lb, const double *__restrict__ ub, const uint8_t *__restrict__ mask, const int *__restrict__ pos, const double *__restrict__ b0full, const double *__restrict__ F, const double *__restrict__ sol, double *__restrict__ dx, double *__restrict__ dy, double *__restrict__ xn, double *__restrict__ yn, double *__restrict__ red) {
+  b_step_update(n, m, nI, fact, rho, x, y, lb, ub, mask, pos, b0full, F, sol, dx, dy, xn, yn, red);
+}
+
+__global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__ red, int cnt, double *__restrict__ out, int take_sqrt) {
+  b_final_reduce(red, cnt, out, take_sqrt);
+}
+
+__global__ __launch_bounds__(256) void k_gemv_rows(int rows, int cols, const double *__restrict__ M, int64_t ld, const double *__restrict__ v, const double *__restrict__ add, double sgn, double *__restrict__ out) {
+  b_gemv_rows(rows, cols, M, ld, v, add, sgn, out);
+}
+
+__global__ __launch_bounds__(256) void k_gemvT_partial(int rows, int cols, const double *__restrict__ M, int64_t ld, const double *__restrict__ w, int chunk, double *__restrict__ partial) {
+  b_gemvT_partial(rows, cols, M, ld, w, chunk, partial);
+}
+
+__global__ void k_sum_partials(int cols, int nparts, const double *__restrict__ partial, const double *__restrict__ base, double *__restrict__ out) {
+  b_sum_partials(cols, nparts, partial, base, out);
+}
+
+__global__ void k_mult_vec(int m, double rho, const double *__restrict__ c, const double *__restrict__ y, double *__restrict__ w) {
+  b_mult_vec(m, rho, c, y, w);
+}
+
+__global__ __launch_bounds__(256) void k_unscaled_res_sq(int n, int m, double dt, const double *__restrict__ xhat, const double *__restrict__ yhat, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ g, const double *__restrict__ c, const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ red) {
+  b_unscaled_res_sq(n, m, dt, xhat, yhat, x, y, g, c, lb, ub, red);
 }
 
 // ---------------------------------------------------------------- launch wrappers
@@ -459,4 +526,209 @@ void launch_unscaled_res_norm(hipStream_t s, int n, int m, double dt, const doub
 
 void launch_final_reduce(hipStream_t s, const double *red, int cnt, double *out, int take_sqrt) {
   hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(256), 0, s, red, cnt, out, take_sqrt);
+}
+
+// ================================================================ batched kernels
+// Same bodies as above, one instance per blockIdx.z, sizes read on the device (BInst in
+// pgf_internal.h).  Nothing here needs a host round trip.
+__global__ void kb_advance(const BInst *__restrict__ tab, int n, int m, double lamb) {
+  const BInst &I = tab[blockIdx.z];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    I.xhat[i] = I.x[i];
+    I.slb[i] = lamb * I.lb[i];
+    I.sub[i] = lamb * I.ub[i];
+  } else if (i < n + m) {
+    I.yhat[i - n] = I.y[i - n];
+  }
+  if (i == 0) {
+    I.ctl[0] = 0;
+    I.ctl[1] = 0;
+    I.ctl[2] = 0;
+  }
+}
+
+// which 0: c = J x - b ; which 1: g = H x + tmpn
+__global__ __launch_bounds__(256) void kb_gemv_rows(const BInst *__restrict__ tab, int which,
+                                                    int n, int m) {
+  const BInst &I = tab[blockIdx.z];
+  if (which == 0)
+    b_gemv_rows(m, n, I.J, I.ldj, I.x, I.b, -1.0, I.c);
+  else
+    b_gemv_rows(n, n, I.H, I.ldh, I.x, I.tmpn, 1.0, I.g);
+}
+
+__global__ void kb_mult_vec(const BInst *__restrict__ tab, int m, double rho) {
+  const BInst &I = tab[blockIdx.z];
+  b_mult_vec(m, rho, I.c, I.y, I.w);
+}
+
+__global__ __launch_bounds__(256) void kb_gemvT_partial(const BInst *__restrict__ tab, int n, int m,
+                                                        int chunk) {
+  const BInst &I = tab[blockIdx.z];
+  b_gemvT_partial(m, n, I.J, I.ldj, I.w, chunk, I.partial);
+}
+
+__global__ void kb_sum_partials(const BInst *__restrict__ tab, int n, int used) {
+  const BInst &I = tab[blockIdx.z];
+  b_sum_partials(n, used, I.partial, I.q, I.tmpn);
+}
+
+__global__ void kb_active_set(const BInst *__restrict__ tab, int n, int use_tau, double lamb,
+                              double f_x, double f_x0, double f_d) {
+  const BInst &I = tab[blockIdx.z];
+  b_active_set(n, use_tau, lamb, f_x, f_x0, f_d, I.xhat, I.x, I.g, I.slb, I.sub, I.mask_new);
+}
+
+// Adopt mask_new (mode 2: always; mode 1: when it differs elementwise from the current mask
+// or there is none yet -- newton.py:203-215; mode 0: keep), rebuild the index lists when
+// adopted, and decide whether this step factorises: ctl[0] = !factor_valid.
+__global__ __launch_bounds__(1024) void kb_mask_adopt(const BInst *__restrict__ tab, int n,
+                                                      int mode) {
+  const BInst &I = tab[blockIdx.z];
+  const int tid = threadIdx.x;
+  int diff = 0;
+  if (mode == 2 || (mode == 1 && I.ctl[2] == 0)) {
+    diff = 1;
+  } else if (mode == 1) {
+    for (int j = tid; j < n; j += 1024) diff |= (I.mask[j] != I.mask_new[j]) ? 1 : 0;
+  }
+  const int changed = __syncthreads_or(diff);
+  if (changed) {
+    for (int j = tid; j < n; j += 1024) I.mask[j] = I.mask_new[j];
+    b_compact(n, I.mask_new, I.idxI, I.idxA, I.pos, I.counts);
+  }
+  if (tid == 0) {
+    if (changed) {
+      I.ctl[2] = 1;
+      I.ctl[1] = 0;
+    }
+    I.ctl[0] = (changed || I.ctl[1] == 0) ? 1 : 0;
+  }
+}
+
+__global__ void kb_residual(const BInst *__restrict__ tab, int n, int m, double lamb, double dt) {
+  const BInst &I = tab[blockIdx.z];
+  b_residual(n, m, lamb, dt, I.xhat, I.yhat, I.x, I.y, I.g, I.c, I.slb, I.sub, I.mask, I.F,
+             I.b0full);
+}
+
+__global__ __launch_bounds__(256) void kb_reduced_rhs(const BInst *__restrict__ tab, int n, int m,
+                                                      double fact) {
+  const BInst &I = tab[blockIdx.z];
+  b_reduced_rhs(n, m, I.counts[0], I.counts[1], fact, I.F, I.idxI, I.H, I.ldh, I.J, I.ldj,
+                I.b0full, I.rhs);
+}
+
+// K (lower triangle) + the right-hand side in row N, only for instances that factorise
+__global__ __launch_bounds__(256) void kb_assemble(const BInst *__restrict__ tab, int m,
+                                                   double lamb, double delta) {
+  const BInst &I = tab[blockIdx.z];
+  if (I.ctl[0] == 0) return;
+  const int nI = I.counts[0], N = nI + m;
+  const int i = blockIdx.y;
+  if (i > N) return;
+  if (i == 0 && blockIdx.x == 0 && threadIdx.x < 4) I.flags[threadIdx.x] = 0;
+  if (i == N) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < N) I.K[(int64_t)N * I.ldk + j] = I.rhs[j];
+    return;
+  }
+  b_assemble_kkt(I.K, I.ldk, I.H, I.ldh, I.J, I.ldj, I.idxI, nI, m, lamb, delta);
+}
+
+__global__ __launch_bounds__(256) void kb_step_update(const BInst *__restrict__ tab, int n, int m,
+                                                      double fact, double rho) {
+  const BInst &I = tab[blockIdx.z];
+  b_step_update(n, m, I.counts[0], fact, rho, I.x, I.y, I.lb, I.ub, I.mask, I.pos, I.b0full, I.F,
+                I.sol, I.dx, I.dy, I.xn, I.yn, I.red);
+  // the new point replaces the current one in place (each lane re-reads its own entry)
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n)
+    I.x[i] = I.xn[i];
+  else if (i < n + m)
+    I.y[i - n] = I.yn[i - n];
+}
+
+__global__ __launch_bounds__(256) void kb_step_final(const BInst *__restrict__ tab, int nb,
+                                                     double *__restrict__ diff_out,
+                                                     int *__restrict__ flags_out) {
+  const BInst &I = tab[blockIdx.z];
+  b_final_reduce(I.red, nb, diff_out + blockIdx.z, 1);
+  if (threadIdx.x == 0) {
+    flags_out[2 * blockIdx.z] = I.flags[0];
+    flags_out[2 * blockIdx.z + 1] = I.flags[1];
+    if (I.ctl[0]) I.ctl[1] = (I.flags[0] == 0) ? 1 : 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void kb_unscaled_res_sq(const BInst *__restrict__ tab, int n,
+                                                          int m, double dt) {
+  const BInst &I = tab[blockIdx.z];
+  b_unscaled_res_sq(n, m, dt, I.xhat, I.yhat, I.x, I.y, I.g, I.c, I.lb, I.ub, I.red);
+}
+
+__global__ __launch_bounds__(256) void kb_norm_final(const BInst *__restrict__ tab, int nb,
+                                                     double *__restrict__ norm_out) {
+  const BInst &I = tab[blockIdx.z];
+  b_final_reduce(I.red, nb, norm_out + blockIdx.z, 1);
+}
+
+static inline dim3 gb(int cnt, int per, int B) { return dim3((cnt + per - 1) / per, 1, B); }
+
+void batch_launch_advance(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc) {
+  if (sc.n + sc.m)
+    hipLaunchKernelGGL(kb_advance, gb(sc.n + sc.m, 256, B), dim3(256), 0, s, tab, sc.n, sc.m,
+                       sc.lamb);
+}
+
+// c = A x - b ; w = rho c + y ; tmpn = q + A' w ; g = Q x + tmpn   for every instance
+void batch_launch_eval(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc, int nparts) {
+  const int n = sc.n, m = sc.m;
+  if (!n) return;
+  int used = 0;
+  if (m) {
+    hipLaunchKernelGGL(kb_gemv_rows, gb(m, 4, B), dim3(256), 0, s, tab, 0, n, m);
+    hipLaunchKernelGGL(kb_mult_vec, gb(m, 256, B), dim3(256), 0, s, tab, m, sc.rho);
+    const int chunk = (m + nparts - 1) / nparts;
+    used = (m + chunk - 1) / chunk;
+    hipLaunchKernelGGL(kb_gemvT_partial, dim3((n + 255) / 256, used, B), dim3(256), 0, s, tab, n, m,
+                       chunk);
+  }
+  hipLaunchKernelGGL(kb_sum_partials, gb(n, 256, B), dim3(256), 0, s, tab, n, used);
+  hipLaunchKernelGGL(kb_gemv_rows, gb(n, 4, B), dim3(256), 0, s, tab, 1, n, m);
+}
+
+void batch_launch_mask(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc, int mode,
+                       int use_tau, double f_x, double f_x0, double f_d) {
+  if (mode != 0 && sc.n)
+    hipLaunchKernelGGL(kb_active_set, gb(sc.n, 256, B), dim3(256), 0, s, tab, sc.n, use_tau, sc.lamb,
+                       f_x, f_x0, f_d);
+  hipLaunchKernelGGL(kb_mask_adopt, dim3(1, 1, B), dim3(1024), 0, s, tab, sc.n, mode);
+}
+
+void batch_launch_rhs_assemble(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc) {
+  const int n = sc.n, m = sc.m, Nmax = n + m;
+  if (!Nmax) return;
+  hipLaunchKernelGGL(kb_residual, gb(Nmax, 256, B), dim3(256), 0, s, tab, n, m, sc.lamb, sc.dt);
+  hipLaunchKernelGGL(kb_reduced_rhs, gb(Nmax, 4, B), dim3(256), 0, s, tab, n, m, sc.fact);
+  hipLaunchKernelGGL(kb_assemble, dim3((Nmax + 255) / 256, Nmax + 1, B), dim3(256), 0, s, tab, m,
+                     sc.lamb, sc.delta);
+}
+
+void batch_launch_step_update(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc,
+                              double *diff_out, int *flags_out) {
+  const int nb = step_update_blocks(sc.n, sc.m);
+  if (nb)
+    hipLaunchKernelGGL(kb_step_update, dim3(nb, 1, B), dim3(256), 0, s, tab, sc.n, sc.m, sc.fact,
+                       sc.rho);
+  hipLaunchKernelGGL(kb_step_final, dim3(1, 1, B), dim3(256), 0, s, tab, nb, diff_out, flags_out);
+}
+
+void batch_launch_res_norm(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc,
+                           double *norm_out) {
+  const int nb = (sc.n + sc.m + 255) / 256;
+  if (nb)
+    hipLaunchKernelGGL(kb_unscaled_res_sq, dim3(nb, 1, B), dim3(256), 0, s, tab, sc.n, sc.m, sc.dt);
+  hipLaunchKernelGGL(kb_norm_final, dim3(1, 1, B), dim3(256), 0, s, tab, nb, norm_out);
 }

@@ -868,9 +868,9 @@ __global__ __launch_bounds__(256, 2) void k_ldlt_panel_fused(
 // L_bb^T is broadcast from LDS.  Stored twice, inv(L_bb) and its transpose, both as
 // [block][row][64], so that forward and backward solves read coalesced rows.
 // The triangular solves then need no serial 63-step chain per block, only mat-vecs.
-__global__ __launch_bounds__(64) void k_inv_diag_blocks(const double *__restrict__ K, int64_t ldk,
-                                                        int N, double *__restrict__ Linv,
-                                                        double *__restrict__ LinvT) {
+__device__ __forceinline__ void inv_diag_body(const double *__restrict__ K, int64_t ldk, int N,
+                                              double *__restrict__ Linv,
+                                              double *__restrict__ LinvT) {
   __shared__ __attribute__((aligned(16))) double Lt[64][64];  // Lt[t][j] = L_bb[j][t], j > t
   const int lane = threadIdx.x;
   const int b0 = blockIdx.x * 64;
@@ -910,10 +910,10 @@ __global__ __launch_bounds__(64) void k_inv_diag_blocks(const double *__restrict
 //     operands prefetched one sub-block ahead) and publishes the solved sub-block in LDS;
 //   * after a barrier each wavefront folds the solved values into its target entries.
 template <int SUPER>
-__global__ __launch_bounds__(256) void k_trsv_bwd_super(const double *__restrict__ K, int64_t ldk,
-                                                         const double *__restrict__ Linv,
-                                                         double *__restrict__ z,
-                                                         double *__restrict__ x, int N, int c0) {
+__device__ __forceinline__ void trsv_bwd_body(const double *__restrict__ K, int64_t ldk,
+                                              const double *__restrict__ Linv,
+                                              double *__restrict__ z, double *__restrict__ x,
+                                              int N, int c0) {
   static_assert(SUPER == 256, "four sub-blocks, four wavefronts");
   __shared__ double zs[SUPER];  // work entries of the super-block
   __shared__ double xs[64];     // solved sub-block
@@ -979,10 +979,10 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_super(const double *__restrict
 // then folds into this workgroup's own 64 rows below the super-block; wavefront q > sb
 // folds into the later sub-block q of the same super-block (redundantly per workgroup).
 template <int SUPER>
-__global__ __launch_bounds__(256) void k_trsv_fwd_super(const double *__restrict__ K, int64_t ldk,
-                                                         const double *__restrict__ LinvT,
-                                                         double *__restrict__ z,
-                                                         double *__restrict__ x, int N, int c0) {
+__device__ __forceinline__ void trsv_fwd_body(const double *__restrict__ K, int64_t ldk,
+                                              const double *__restrict__ LinvT,
+                                              double *__restrict__ z, double *__restrict__ x,
+                                              int N, int c0) {
   static_assert(SUPER == 256, "four sub-blocks, four wavefronts");
   __shared__ double zs[SUPER];
   __shared__ double xs[64];
@@ -1045,6 +1045,111 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_super(const double *__restrict
     __syncthreads();
   }
   if (ext_live) z[r] = zext;
+}
+
+__global__ __launch_bounds__(64) void k_inv_diag_blocks(const double *__restrict__ K, int64_t ldk,
+                                                        int N, double *__restrict__ Linv,
+                                                        double *__restrict__ LinvT) {
+  inv_diag_body(K, ldk, N, Linv, LinvT);
+}
+
+template <int SUPER>
+__global__ __launch_bounds__(256) void k_trsv_bwd_super(const double *__restrict__ K, int64_t ldk,
+                                                         const double *__restrict__ Linv,
+                                                         double *__restrict__ z,
+                                                         double *__restrict__ x, int N, int c0) {
+  trsv_bwd_body<SUPER>(K, ldk, Linv, z, x, N, c0);
+}
+
+template <int SUPER>
+__global__ __launch_bounds__(256) void k_trsv_fwd_super(const double *__restrict__ K, int64_t ldk,
+                                                         const double *__restrict__ LinvT,
+                                                         double *__restrict__ z,
+                                                         double *__restrict__ x, int N, int c0) {
+  trsv_fwd_body<SUPER>(K, ldk, LinvT, z, x, N, c0);
+}
+
+// ------------------------------------------------------------------ batched variants
+// One instance per blockIdx.z (BInst, pgf_internal.h).  Every instance has its own reduced
+// size N = counts[0] + m, known only on the device: the host walks the panel / update
+// schedule of the largest possible system (n + m) and workgroups beyond an instance's own
+// N return at once.  ctl[0] == 0 (factor still valid) skips the factorisation kernels.
+template <int NB>
+__global__ __launch_bounds__(256) void kb_ldlt_panel(const BInst *__restrict__ tab, int m,
+                                                     int64_t ldw, int wbuf, int ob0, int c0) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[PNL_SMEM];
+  const BInst &I = tab[blockIdx.z];
+  if (I.ctl[0] == 0) return;
+  const int N = I.counts[0] + m, nrows = N + 1;
+  if (c0 >= N) return;
+  const int below = nrows - min(c0 + NB, N);
+  const int npw = max(1, (below + 63) / 64);
+  if ((int)blockIdx.x >= npw) return;
+  panel_body<NB>(smem, blockIdx.x, I.K, I.ldk, I.W + (int64_t)wbuf * I.wstride, ldw, c0 - ob0, N,
+                 nrows, c0, I.dvec, I.dinv, I.flags, 0);
+}
+
+__global__ __launch_bounds__(256) void kb_ldlt_update(const BInst *__restrict__ tab, int m,
+                                                      int64_t ldw, int wbuf, int wcol, int row0,
+                                                      int col0, int colEndArg, int kc0, int KB) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(64 + 64) * (16 + 2) * 8];
+  const BInst &I = tab[blockIdx.z];
+  if (I.ctl[0] == 0) return;
+  const int N = I.counts[0] + m, nrows = N + 1;
+  const int colEnd = min(colEndArg, N);
+  const int i0 = row0 + blockIdx.y * 64;
+  const int j0 = col0 + blockIdx.x * 64;
+  if (i0 >= nrows || j0 >= colEnd || j0 > i0 + 63) return;
+  update_tile<64, 64, 16>(smem, i0, j0, I.K, I.ldk, I.W + (int64_t)wbuf * I.wstride + wcol, ldw, N,
+                          nrows, colEnd, kc0, KB);
+}
+
+__global__ __launch_bounds__(64) void kb_inv_diag_blocks(const BInst *__restrict__ tab, int m) {
+  const BInst &I = tab[blockIdx.z];
+  if (I.ctl[0] == 0) return;
+  const int N = I.counts[0] + m;
+  if ((int)blockIdx.x * 64 >= N) return;
+  inv_diag_body(I.K, I.ldk, N, I.Linv, I.LinvT);
+}
+
+// forward half for instances whose factor is reused: zwork <- rhs
+__global__ void kb_solve_prep_fwd(const BInst *__restrict__ tab, int m) {
+  const BInst &I = tab[blockIdx.z];
+  if (I.ctl[0] != 0) return;
+  const int N = I.counts[0] + m;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) I.zwork[i] = I.rhs[i];
+}
+
+__global__ __launch_bounds__(256) void kb_trsv_fwd_super(const BInst *__restrict__ tab, int m,
+                                                         int c0) {
+  const BInst &I = tab[blockIdx.z];
+  if (I.ctl[0] != 0) return;
+  const int N = I.counts[0] + m;
+  if (c0 >= N) return;
+  const int below = N - (c0 + 256);
+  const int g = below > 0 ? (below + 63) / 64 : 1;
+  if ((int)blockIdx.x >= g) return;
+  trsv_fwd_body<256>(I.K, I.ldk, I.LinvT, I.zwork, I.sol, N, c0);
+}
+
+// zwork <- D^-1 L^-1 rhs: row N of K after a factorisation, D^-1 * (forward result) otherwise
+__global__ void kb_solve_prep_bwd(const BInst *__restrict__ tab, int m) {
+  const BInst &I = tab[blockIdx.z];
+  const int N = I.counts[0] + m;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  I.zwork[i] = I.ctl[0] ? I.K[(int64_t)N * I.ldk + i] : I.sol[i] * I.dinv[i];
+}
+
+__global__ __launch_bounds__(256) void kb_trsv_bwd_super(const BInst *__restrict__ tab, int m,
+                                                         int c0) {
+  const BInst &I = tab[blockIdx.z];
+  const int N = I.counts[0] + m;
+  if (c0 >= N) return;
+  const int g = c0 > 0 ? (c0 + 63) / 64 : 1;
+  if ((int)blockIdx.x >= g) return;
+  trsv_bwd_body<256>(I.K, I.ldk, I.Linv, I.zwork, I.sol, N, c0);
 }
 
 __global__ void k_vec_scale(double *__restrict__ z, const double *__restrict__ dinv, int N) {
@@ -1372,6 +1477,53 @@ hipError_t ldlt_solve_async(DenseLdlt &f, const double *rhs, double *sol) {
   hipLaunchKernelGGL(k_vec_scale, dim3((N + 255) / 256), dim3(256), 0, s, sol, f.dinv, N);
   // backward: L^T s = y
   return ldlt_backsolve_async(f, sol, sol);
+}
+
+// ------------------------------------------------------------------ batched host schedule
+void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m, int OB) {
+  if (Nmax <= 0 || B <= 0) return;
+  int buf = 0;
+  for (int ob0 = 0; ob0 < Nmax; ob0 += OB, buf ^= 1) {
+    const int obEnd = std::min(ob0 + OB, Nmax);
+    for (int c0 = ob0; c0 < obEnd; c0 += PGF_NB) {
+      const int below = Nmax + 1 - std::min(c0 + PGF_NB, Nmax);
+      const int npw = std::max(1, (below + 63) / 64);
+      hipLaunchKernelGGL(kb_ldlt_panel<PGF_NB>, dim3(npw, 1, B), dim3(256), 0, s, tab, m,
+                         (int64_t)OB, buf, ob0, c0);
+      const int c1 = c0 + PGF_NB;
+      if (c1 < obEnd) {
+        const int tr = (Nmax + 1 - c1 + 63) / 64, tc = (obEnd - c1 + 63) / 64;
+        hipLaunchKernelGGL(kb_ldlt_update, dim3(tc, tr, B), dim3(256), 0, s, tab, m, (int64_t)OB,
+                           buf, c0 - ob0, c1, c1, ob0 + OB, c0, PGF_NB);
+      }
+    }
+    if (obEnd < Nmax) {
+      const int tr = (Nmax + 1 - obEnd + 63) / 64, tc = (Nmax - obEnd + 63) / 64;
+      hipLaunchKernelGGL(kb_ldlt_update, dim3(tc, tr, B), dim3(256), 0, s, tab, m, (int64_t)OB, buf,
+                         0, obEnd, obEnd, 0x7fffffff, ob0, OB);
+    }
+  }
+  hipLaunchKernelGGL(kb_inv_diag_blocks, dim3((Nmax + 63) / 64, 1, B), dim3(64), 0, s, tab, m);
+}
+
+void ldlt_batch_solve_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m,
+                            bool any_unfactored_solve) {
+  if (Nmax <= 0 || B <= 0) return;
+  const dim3 gv((Nmax + 255) / 256, 1, B);
+  if (any_unfactored_solve) {
+    hipLaunchKernelGGL(kb_solve_prep_fwd, gv, dim3(256), 0, s, tab, m);
+    for (int c0 = 0; c0 < Nmax; c0 += 256) {
+      const int below = Nmax - (c0 + 256);
+      const int g = below > 0 ? (below + 63) / 64 : 1;
+      hipLaunchKernelGGL(kb_trsv_fwd_super, dim3(g, 1, B), dim3(256), 0, s, tab, m, c0);
+    }
+  }
+  hipLaunchKernelGGL(kb_solve_prep_bwd, gv, dim3(256), 0, s, tab, m);
+  const int last = ((Nmax - 1) / 256) * 256;
+  for (int c0 = last; c0 >= 0; c0 -= 256) {
+    const int g = c0 > 0 ? (c0 + 63) / 64 : 1;
+    hipLaunchKernelGGL(kb_trsv_bwd_super, dim3(g, 1, B), dim3(256), 0, s, tab, m, c0);
+  }
 }
 
 // ------------------------------------------------------------------ micro-benchmark

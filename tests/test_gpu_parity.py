@@ -257,6 +257,75 @@ def test_batched_single_rank(pgf):
     bd.close()
 
 
+@pytest.mark.parametrize("kind", ["Full", "ActiveSet", "Simplified"])
+def test_device_batch_matches_per_instance(pgf, kind):
+    """pgf_batch_* (instance = blockIdx.z, sizes read on device) against the same instances
+    driven one by one through their own handles: boxed variables make the active sets, and
+    with them the reduced sizes N_i, differ between instances.  Masks and inertia identical,
+    points to 1e-13 (same kernels, same summation order), over two outer steps."""
+    from pygradflow_amd import problems
+    from pygradflow_amd.batched import BatchedDeviceNewton
+
+    B, n, m = 5, 200, 56
+
+    def make(i):
+        return problems.dense_qp(n, m, seed=10 + i, boxed_frac=0.1 * i, box=0.02)
+
+    bd = BatchedDeviceNewton(make, B, kind, 0.5, 1.0)
+    ref = BatchedDeviceNewton(make, B, kind, 0.5, 1.0, sequential=True)
+    for s in ref.solvers:  # the sequential driver starts its outer step the same way
+        s.advance_outer(0.5, 1.0)
+    sizes = set()
+    for outer in range(2):
+        for k in range(3):
+            st, nn, df = bd.step_local()
+            st2, nn2, df2 = ref.step_local()
+            assert not st.any()
+            mk, mk2 = bd.masks(), ref.masks()
+            assert np.array_equal(mk, mk2), (outer, k)
+            assert np.array_equal(nn, nn2), (outer, k)
+            assert (nn == m).all()
+            x, y = bd.points()
+            x2, y2 = ref.points()
+            assert G.rel_err(x, x2) <= 1e-13 and G.rel_err(y, y2) <= 1e-13, (outer, k)
+            assert np.allclose(df, df2, rtol=1e-12, atol=0)
+            nb = bd.norms[:B].cpu().numpy()
+            nr = ref.norms[:B].cpu().numpy()
+            assert np.allclose(nb, nr, rtol=1e-12, atol=1e-300)
+            sizes.update(int(n - row.sum()) for row in mk)
+        bd.advance_outer(0.25, 1.0)
+        ref.advance_outer(0.25, 1.0)
+    assert len(sizes) > 1  # instances really had different reduced sizes
+    bd.close()
+    ref.close()
+
+
+def test_device_batch_against_oracle(pgf):
+    """Batched Full steps at the config-4 instance shape (n=1024, m=256, reduced size 1280:
+    five outer blocks of the factorisation) against the CPU restatement, per instance."""
+    from pygradflow_amd import problems
+    from pygradflow_amd.batched import BatchedDeviceNewton
+    B, n, m = 3, 1024, 256
+
+    def make(i):
+        return problems.dense_qp(n, m, seed=i, boxed_frac=0.25 if i == 1 else 0.0)
+
+    bd = BatchedDeviceNewton(make, B, "Full", 1.0, 1.0)
+    ors = [O.NewtonOracle(make(i), "Full", np.zeros(n), np.zeros(m), 1.0, 1.0) for i in range(B)]
+    pts = [(np.zeros(n), np.zeros(m)) for _ in range(B)]
+    for k in range(2):
+        st, nn, df = bd.step_local()
+        assert not st.any() and (nn == m).all()
+        x, y = bd.points()
+        mk = bd.masks()
+        for i in range(B):
+            xn, yn, _ = ors[i].step(*pts[i])
+            pts[i] = (xn, yn)
+            assert np.array_equal(mk[i], ors[i].solver.record["mask"]), (k, i)
+            assert G.rel_err(x[i], xn) <= TOL and G.rel_err(y[i], yn) <= TOL, (k, i)
+    bd.close()
+
+
 # ------------------------------------------------------------------ sparse (banded) path
 def _as_sparse_lq(problem):
     from pygradflow_amd import problems
