@@ -100,7 +100,7 @@ __device__ __forceinline__ double fast_recip(double d) {
 
 #define PNL_SMEM (128 * PNL_LD * 8 + 128 * PNL_WLD * 8 + 2 * 64 * 8 + 16)
 
-template <int NB>
+template <int NB, bool PRE = false>
 __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
                                            double *__restrict__ K, int64_t ldk,
                                            double *__restrict__ W, int64_t ldw, int wofs, int N,
@@ -122,8 +122,8 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
 
   // ---- load: diag block (identity outside the valid lower triangle) + own rows.
   // All 16 global loads of a lane are issued before the first LDS store (one memory
-  // latency instead of sixteen).
-  {
+  // latency instead of sixteen).  PRE: the caller has filled M already.
+  if (!PRE) {
     double2_t v[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_super(const double *__restrict
 // with its own L2.  Instance i is pinned to XCD i % 8 (id % 8 selects the residue class, the
 // rest of the id walks that class instance by instance, tile by tile), so the tiles of one
 // instance that run together share one L2 instead of every L2 seeing every instance:
-// without this the batched trailing update re-reads its panels from HBM (9 -> 30 TFLOP/s).
+// measured on the K = 256 trailing update of 256 instances: 19.7 -> 29.9 TFLOP/s.
 __device__ __forceinline__ bool batch_decode(int B, int per, int &inst, int &t) {
   const int id = blockIdx.x;
   const int slot = id >> 3;
@@ -1124,6 +1124,258 @@ __global__ __launch_bounds__(256) void kb_ldlt_update(const BInst *__restrict__ 
   if (i0 >= nrows || j0 >= colEnd || j0 > i0 + 63) return;
   update_tile<64, 64, 16>(smem, i0, j0, I.K, I.ldk, I.W + (int64_t)wbuf * I.wstride + wcol, ldw, N,
                           nrows, colEnd, kc0, KB);
+}
+
+// ---- left-looking panel step of the batched schedule --------------------------------------
+// In batched mode throughput counts, not the latency of one panel, so the panel step is split:
+//   kb_diag_ll : ONE workgroup per instance brings the 64 x 64 diagonal tile up to date with
+//                the earlier panels of its outer block (left-looking, MFMA), factorises it
+//                (panel_body on a preloaded tile) and inverts the unit-lower factor;
+//   kb_trsm_ll : one workgroup per 64 rows below: left-looking update of its tile, then
+//                X = T inv(L_bb)^T as a 64^3 MFMA product; stores W = X and L = X D^-1.
+// No workgroup repeats the diagonal factorisation and there are no K = 64 trailing updates
+// (their C traffic and launches are gone); the inverses are the ones the triangular solves
+// need anyway.
+#define LL_LD 66
+#define TRSM_SMEM (2 * 64 * LL_LD * 8 + 64 * 8)
+
+// acc (2 x 2 MFMA tiles per wavefront, quadrant (wr, wc) of a 64 x 64 tile) -=
+//   sum_k A[i0 + i][k] * B[j0 + j][kb0 + k], k < kp, through the LDS staging area `stg`
+__device__ __forceinline__ void ll_accumulate(double4_t (&acc)[2][2], unsigned char *stg,
+                                              const double *__restrict__ A, int64_t lda, int i0,
+                                              int ilim, const double *__restrict__ Bm, int64_t ldb,
+                                              int j0, int jlim, int kb0, int kp) {
+  constexpr int LD = 18;
+  double(*As)[LD] = reinterpret_cast<double(*)[LD]>(stg);
+  double(*Bs)[LD] = reinterpret_cast<double(*)[LD]>(stg + 64 * LD * 8);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, l15 = lane & 15, l4 = lane >> 4;
+  // 64 rows x 8 double2 pieces = 512 pieces per operand: two per lane
+  double2_t pa[2], pb[2];
+  auto fetch = [&](int kk) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int p = q * 256 + tid;
+      const int row = p >> 3, kofs = (p & 7) * 2;
+      double2_t va = (double2_t){0.0, 0.0}, vb = (double2_t){0.0, 0.0};
+      if (i0 + row < ilim)
+        va = *reinterpret_cast<const double2_t *>(A + (int64_t)(i0 + row) * lda + kk + kofs);
+      if (j0 + row < jlim)
+        vb = *reinterpret_cast<const double2_t *>(Bm + (int64_t)(j0 + row) * ldb + kb0 + kk + kofs);
+      pa[q] = va;
+      pb[q] = vb;
+    }
+  };
+  if (kp > 0) fetch(0);
+  for (int kk = 0; kk < kp; kk += 16) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int p = q * 256 + tid;
+      *reinterpret_cast<double2_t *>(&As[p >> 3][(p & 7) * 2]) = -pa[q];
+      *reinterpret_cast<double2_t *>(&Bs[p >> 3][(p & 7) * 2]) = pb[q];
+    }
+    __syncthreads();
+    if (kk + 16 < kp) fetch(kk + 16);
+#pragma unroll
+    for (int ks = 0; ks < 16; ks += 4) {
+      double a[2], b[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = As[wr * 32 + t * 16 + l15][ks + l4];
+        b[t] = Bs[wc * 32 + t * 16 + l15][ks + l4];
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+          acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
+    }
+  }
+  __syncthreads();  // staging area free again
+}
+
+__global__ __launch_bounds__(256) void kb_diag_ll(const BInst *__restrict__ tab, int m, int64_t ldw,
+                                                  int wbuf, int ob0, int c0) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[PNL_SMEM];
+  const BInst &I = tab[blockIdx.x];  // workgroup i -> XCD i % 8, as batch_decode pins it
+  if (I.ctl[0] == 0) return;
+  const int N = I.counts[0] + m;
+  if (c0 >= N) return;
+  const int nb = min(64, N - c0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, l15 = lane & 15, l4 = lane >> 4;
+  double(*M)[PNL_LD] = reinterpret_cast<double(*)[PNL_LD]>(smem);
+  const double *Wb = I.W + (int64_t)wbuf * I.wstride;
+  // lower triangle of the diagonal tile, updated by the panels [ob0, c0) of this outer block
+  double4_t acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+      const int j = wc * 32 + nj * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = wr * 32 + mi * 16 + l4 + 4 * r;
+        acc[mi][nj][r] = (i < nb && j <= i) ? I.K[(int64_t)(c0 + i) * I.ldk + c0 + j] : 0.0;
+      }
+    }
+  ll_accumulate(acc, smem + 64 * PNL_LD * 8, Wb, ldw, c0, c0 + nb, I.K, I.ldk, c0, c0 + nb, ob0,
+                c0 - ob0);
+  // M rows 0..63 <- tile (identity outside the valid lower triangle), rows 64..127 <- 0
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+      const int j = wc * 32 + nj * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = wr * 32 + mi * 16 + l4 + 4 * r;
+        double v = acc[mi][nj][r];
+        if (i >= nb) v = (i == j) ? 1.0 : 0.0;
+        else if (j > i) v = 0.0;
+        M[i][j] = v;
+      }
+    }
+  for (int p = tid; p < 64 * 32; p += 256)
+    *reinterpret_cast<double2_t *>(&M[64 + (p >> 5)][(p & 31) * 2]) = (double2_t){0.0, 0.0};
+  __syncthreads();
+  // factorise in place (no rows below: nrows = c0 + nb); writes the tile, D, 1/D, flags
+  panel_body<PGF_NB, true>(smem, 0, I.K, I.ldk, I.W + (int64_t)wbuf * I.wstride, ldw, c0 - ob0, N,
+                           c0 + nb, c0, I.dvec, I.dinv, I.flags, 0);
+  __syncthreads();
+  // inverse of the unit-lower factor: lane c of wavefront 0 owns column c (substitution on
+  // e_c, L broadcast from LDS); rows >= nb of M are identity rows, so is their inverse
+  double(*Tt)[PNL_LD] = reinterpret_cast<double(*)[PNL_LD]>(smem + 64 * PNL_LD * 8);
+  const size_t blk = (size_t)(c0 / 64) * 4096;
+  if (wave == 0) {
+    double y[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) y[j] = (j == lane) ? 1.0 : 0.0;
+#pragma unroll
+    for (int t = 0; t < 63; ++t) {
+      const double yt = y[t];
+#pragma unroll
+      for (int j = t + 1; j < 64; ++j) y[j] = fma(-yt, M[j][t], y[j]);
+    }
+    double *o = I.Linv + blk;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+      o[j * 64 + lane] = y[j];  // row j of the inverse, coalesced
+      Tt[lane][j] = y[j];       // Tt[c][j] = inv[j][c]
+    }
+  }
+  __syncthreads();
+  double *ot = I.LinvT + blk;
+  for (int p = tid; p < 64 * 64; p += 256) ot[p] = Tt[p >> 6][p & 63];
+}
+
+__global__ __launch_bounds__(256, 2) void kb_trsm_ll(const BInst *__restrict__ tab, int B, int per,
+                                                     int m, int64_t ldw, int wbuf, int ob0,
+                                                     int c0) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[TRSM_SMEM];
+  int inst, wg;
+  if (!batch_decode(B, per, inst, wg)) return;
+  const BInst &I = tab[inst];
+  if (I.ctl[0] == 0) return;
+  const int N = I.counts[0] + m, nrows = N + 1;
+  if (c0 >= N) return;
+  const int nb = min(64, N - c0);
+  const int r0 = c0 + nb + wg * 64;
+  if (r0 >= nrows) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, l15 = lane & 15, l4 = lane >> 4;
+  double(*Ts)[LL_LD] = reinterpret_cast<double(*)[LL_LD]>(smem);
+  double(*Is)[LL_LD] = reinterpret_cast<double(*)[LL_LD]>(smem + 64 * LL_LD * 8);
+  double *ds = reinterpret_cast<double *>(smem + 2 * 64 * LL_LD * 8);
+  double *Wb = I.W + (int64_t)wbuf * I.wstride;
+  // inverse of the diagonal factor and 1/D: issued first, consumed after the update loop
+  const double *ip = I.Linv + (size_t)(c0 / 64) * 4096;
+  double2_t iv[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    iv[q] = *reinterpret_cast<const double2_t *>(ip + (size_t)(q * 256 + tid) * 2);
+  const double dv = (tid < nb) ? I.dinv[c0 + tid] : 0.0;
+  // own tile, columns < nb
+  double4_t acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+      const int j = wc * 32 + nj * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = r0 + wr * 32 + mi * 16 + l4 + 4 * r;
+        acc[mi][nj][r] = (i < nrows && j < nb) ? I.K[(int64_t)i * I.ldk + c0 + j] : 0.0;
+      }
+    }
+  ll_accumulate(acc, smem, Wb, ldw, r0, nrows, I.K, I.ldk, c0, c0 + nb, ob0, c0 - ob0);
+  // T and inv(L) to LDS
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Ts[wr * 32 + mi * 16 + l4 + 4 * r][wc * 32 + nj * 16 + l15] = acc[mi][nj][r];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int p = q * 256 + tid;
+    *reinterpret_cast<double2_t *>(&Is[p >> 5][(p & 31) * 2]) = iv[q];
+  }
+  if (tid < 64) ds[tid] = dv;
+  __syncthreads();
+  // X[i][j] = sum_k T[i][k] inv[j][k]
+  double4_t x[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) x[mi][nj] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+  for (int ks = 0; ks < 64; ks += 4) {
+    double a[2], b[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      a[t] = Ts[wr * 32 + t * 16 + l15][ks + l4];
+      b[t] = Is[wc * 32 + t * 16 + l15][ks + l4];
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj)
+        x[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[nj], x[mi][nj], 0, 0, 0);
+  }
+  __syncthreads();  // all reads of Ts done: reuse it for X
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Ts[wr * 32 + mi * 16 + l4 + 4 * r][wc * 32 + nj * 16 + l15] = x[mi][nj][r];
+  __syncthreads();
+  // coalesced stores: W = X (the L D the updates multiply with), L = X D^-1
+  const int wofs = c0 - ob0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int p = q * 256 + tid;
+    const int row = p >> 5, c2 = (p & 31) * 2;
+    const int r = r0 + row;
+    if (r >= nrows || c2 >= nb) continue;
+    const double2_t w = *reinterpret_cast<const double2_t *>(&Ts[row][c2]);
+    double2_t l;
+    l.x = w.x * ds[c2];
+    l.y = w.y * ds[c2 + 1];
+    double *wp = Wb + (int64_t)r * ldw + wofs + c2;
+    double *kp = I.K + (int64_t)r * I.ldk + c0 + c2;
+    if (c2 + 1 < nb) {
+      *reinterpret_cast<double2_t *>(wp) = w;
+      *reinterpret_cast<double2_t *>(kp) = l;
+    } else {
+      wp[0] = w.x;
+      kp[0] = l.x;
+    }
+  }
 }
 
 __global__ __launch_bounds__(64) void kb_inv_diag_blocks(const BInst *__restrict__ tab, int m) {
@@ -1504,12 +1756,21 @@ hipError_t ldlt_solve_async(DenseLdlt &f, const double *rhs, double *sol) {
 // ------------------------------------------------------------------ batched host schedule
 void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m, int OB) {
   if (Nmax <= 0 || B <= 0) return;
+  // PGF_BATCH_LL=0: the single-instance schedule with a batch dimension (fused panel
+  // kernel + K = 64 inner updates); default: the left-looking split panel step
+  const bool ll = !(getenv("PGF_BATCH_LL") && atoi(getenv("PGF_BATCH_LL")) == 0);
   int buf = 0;
   for (int ob0 = 0; ob0 < Nmax; ob0 += OB, buf ^= 1) {
     const int obEnd = std::min(ob0 + OB, Nmax);
     for (int c0 = ob0; c0 < obEnd; c0 += PGF_NB) {
       const int below = Nmax + 1 - std::min(c0 + PGF_NB, Nmax);
       const int npw = std::max(1, (below + 63) / 64);
+      if (ll) {
+        hipLaunchKernelGGL(kb_diag_ll, dim3(B), dim3(256), 0, s, tab, m, (int64_t)OB, buf, ob0, c0);
+        hipLaunchKernelGGL(kb_trsm_ll, dim3(batch_grid(B, npw)), dim3(256), 0, s, tab, B, npw, m,
+                           (int64_t)OB, buf, ob0, c0);
+        continue;
+      }
       hipLaunchKernelGGL(kb_ldlt_panel<PGF_NB>, dim3(batch_grid(B, npw)), dim3(256), 0, s, tab, B,
                          npw, m, (int64_t)OB, buf, ob0, c0);
       const int c1 = c0 + PGF_NB;
@@ -1525,7 +1786,8 @@ void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, i
                          tr, m, (int64_t)OB, buf, 0, obEnd, obEnd, 0x7fffffff, ob0, OB);
     }
   }
-  hipLaunchKernelGGL(kb_inv_diag_blocks, dim3((Nmax + 63) / 64, 1, B), dim3(64), 0, s, tab, m);
+  if (!ll)
+    hipLaunchKernelGGL(kb_inv_diag_blocks, dim3((Nmax + 63) / 64, 1, B), dim3(64), 0, s, tab, m);
 }
 
 void ldlt_batch_solve_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m,
