@@ -262,7 +262,8 @@ def test_device_batch_matches_per_instance(pgf, kind):
     """pgf_batch_* (instance = blockIdx.z, sizes read on device) against the same instances
     driven one by one through their own handles: boxed variables make the active sets, and
     with them the reduced sizes N_i, differ between instances.  Masks and inertia identical,
-    points to 1e-13 (same kernels, same summation order), over two outer steps."""
+    points to 1e-11 (the batched factorisation is left-looking with inverse-based triangular
+    solves, so rounding differs from the per-instance schedule), over two outer steps."""
     from pygradflow_amd import problems
     from pygradflow_amd.batched import BatchedDeviceNewton
 
@@ -287,11 +288,11 @@ def test_device_batch_matches_per_instance(pgf, kind):
             assert (nn == m).all()
             x, y = bd.points()
             x2, y2 = ref.points()
-            assert G.rel_err(x, x2) <= 1e-13 and G.rel_err(y, y2) <= 1e-13, (outer, k)
-            assert np.allclose(df, df2, rtol=1e-12, atol=0)
+            assert G.rel_err(x, x2) <= 1e-11 and G.rel_err(y, y2) <= 1e-11, (outer, k)
+            assert np.allclose(df, df2, rtol=1e-9, atol=1e-11)
             nb = bd.norms[:B].cpu().numpy()
             nr = ref.norms[:B].cpu().numpy()
-            assert np.allclose(nb, nr, rtol=1e-12, atol=1e-300)
+            assert np.allclose(nb, nr, rtol=1e-9, atol=1e-11)
             sizes.update(int(n - row.sum()) for row in mk)
         bd.advance_outer(0.25, 1.0)
         ref.advance_outer(0.25, 1.0)
