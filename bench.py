@@ -87,7 +87,8 @@ def pmc_traffic(kernel):
 
 
 def bench_batched(args, wl, rank, local_rank, world, dist, torch):
-    """BASELINE configs[3]: B independent instances, contiguous shards per rank."""
+    """BASELINE configs[3]: B independent instances, contiguous shards per rank; every rank
+    advances its shard as ONE device batch (pgf_batch_*), one all-gather of norms per step."""
     from pygradflow_amd import problems
     from pygradflow_amd.batched import BatchedDeviceNewton
 
@@ -107,6 +108,22 @@ def bench_batched(args, wl, rank, local_rank, world, dist, torch):
             bd.advance_outer()
         return bd.step()
 
+    # parity of instance 0's first step against the CPU restatement (rank 0, bounded)
+    parity = cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        rate, recs, csteps, cel = cpu_baseline(problems.dense_qp(n, m, seed=0), args.cpu_seconds)
+        bd.step_local()
+        xg, yg = bd.points()
+        r0 = recs[0]
+        rel = lambda a, b: float(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b)))) if b.size else 0.0
+        parity = dict(instance=0,
+                      mask_hamming=int(np.count_nonzero(bd.masks()[0] != r0["mask"])),
+                      iterate_rel_err=max(rel(xg[0], r0["xn"]), rel(yg[0], r0["yn"])))
+        cpu = dict(value=rate, unit="instance Newton steps/s", cores=1, kind="port",
+                   sample=f"{csteps} Full Newton step(s) of ONE n={n} m={m} instance from x0=y0=0 "
+                          f"(scipy bmat + SuperLU splu as the reference calls them; the "
+                          f"reference runs instances in a process pool, so scale by the cores "
+                          f"used), {cel:.1f} s; host has {os.cpu_count()} cores")
     for i in range(args.warmup):
         one_step(i)
     fence()
@@ -119,6 +136,22 @@ def bench_batched(args, wl, rank, local_rank, world, dist, torch):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    roof = None
+    if rank == 0:
+        bd.profile(True)
+        for i in range(args.steps):
+            one_step(i)
+        pr = bd.profile_read()
+        bd.profile(False)
+        if pr["update_launches"] > 0 and pr["update_ms"] > 0:
+            achieved = pr["update_flops"] / (pr["update_ms"] * 1e-3) / 1e12
+            roof = dict(bound="mfma", kernel="kb_ldlt_update", achieved=achieved,
+                        peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=achieved / PEAK_FP64_MFMA_TFLOPS, traffic=pmc_traffic("kb_ldlt_update"),
+                        launches_per_step=pr["update_launches"] / args.steps,
+                        avg_launch_us=1e3 * pr["update_ms"] / pr["update_launches"],
+                        flops_per_step=pr["update_flops"] / args.steps,
+                        step_flops=(bd.hi - bd.lo) * ((n + m) ** 3 / 3.0 + 2.0 * (n + m) ** 2))
     if rank == 0:
         assert norms.numel() == B
         print(json.dumps({
@@ -129,8 +162,9 @@ def bench_batched(args, wl, rank, local_rank, world, dist, torch):
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload, "n": n, "m": m, "instances": B,
                        "instances_per_gpu": bd.hi - bd.lo, "newton_type": "Full",
+                       "path": "device batch (pgf_batch_*, instance = XCD-pinned workgroup range)",
                        "collective": "all_gather(256 residual norms)" if world > 1 else "none"},
-            "roofline": None, "cpu_baseline": None,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         }), flush=True)
     bd.close()
     if dist is not None:

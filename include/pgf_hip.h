@@ -199,6 +199,10 @@ int pgf_batch_residual_norms(pgf_batch b, double *norms_out, double *norms_out_d
 int pgf_batch_get_points(pgf_batch b, double *x, double *y);
 int pgf_batch_get_masks(pgf_batch b, uint8_t *mask);
 int pgf_batch_stream(pgf_batch b, void **stream_out);
+/* as pgf_profile_enable / pgf_profile_read, for the batch's trailing-update launches */
+int pgf_batch_profile_enable(pgf_batch b, int on);
+int pgf_batch_profile_read(pgf_batch b, double *update_ms, int64_t *update_launches,
+                           double *update_flops);
 
 /* ---- stand-alone dense linear solver (LinearSolver ABC) ------------------ */
 /* LinearSolver.__init__ factorises in the constructor

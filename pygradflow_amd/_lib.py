@@ -77,6 +77,8 @@ SIGNATURES = {
     "pgf_batch_get_points": (C.c_int, [_h, _dp, _dp]),
     "pgf_batch_get_masks": (C.c_int, [_h, _u8p]),
     "pgf_batch_stream": (C.c_int, [_h, C.POINTER(C.c_void_p)]),
+    "pgf_batch_profile_enable": (C.c_int, [_h, C.c_int]),
+    "pgf_batch_profile_read": (C.c_int, [_h, _dp, C.POINTER(C.c_int64), _dp]),
     "pgf_ls_create_dense": (C.c_int, [C.c_int, _dp, C.c_int64, C.c_int, C.c_int, C.POINTER(_h)]),
     "pgf_ls_solve": (C.c_int, [_h, _dp, C.c_int, _dp]),
     "pgf_ls_num_neg": (C.c_int, [_h, _ip]),

@@ -179,6 +179,20 @@ class BatchedDeviceNewton:
                         batch=self._b)
         return mk
 
+    def profile(self, on=True):
+        if self._b is not None:
+            self._lib.check(self._lib.load().pgf_batch_profile_enable(self._b, int(on)),
+                            batch=self._b)
+
+    def profile_read(self):
+        """Device time / launches / algorithmic flops of the trailing-update launches."""
+        C = self._C
+        ms, cnt, fl = C.c_double(0), C.c_int64(0), C.c_double(0)
+        if self._b is not None:
+            self._lib.check(self._lib.load().pgf_batch_profile_read(
+                self._b, C.byref(ms), C.byref(cnt), C.byref(fl)), batch=self._b)
+        return dict(update_ms=ms.value, update_launches=cnt.value, update_flops=fl.value)
+
     def close(self):
         if self._b is not None:
             self._lib.load().pgf_batch_destroy(self._b)

@@ -878,6 +878,7 @@ struct pgf_batch_s {
   BatchScalars sc{};
   bool outer_set = false, eval_fresh = false, step_pending = false, have_mask = false;
   bool all_factored = false;
+  PgfProfile prof;
   std::string err = "";
 };
 
@@ -927,10 +928,10 @@ int pgf_batch_create(const pgf_handle *handles, int count, pgf_batch *out) {
   if ((e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipMalloc((void **)&b->tab, count * sizeof(BInst))) != hipSuccess ||
       (e = hipMalloc((void **)&b->ctl, (size_t)count * 4 * sizeof(int))) != hipSuccess ||
-      (e = hipMalloc((void **)&b->flags_out, (size_t)count * 2 * sizeof(int))) != hipSuccess ||
+      (e = hipMalloc((void **)&b->flags_out, (size_t)count * 3 * sizeof(int))) != hipSuccess ||
       (e = hipMalloc((void **)&b->diff_out, count * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void **)&b->norm_out, count * sizeof(double))) != hipSuccess ||
-      (e = hipHostMalloc((void **)&b->h_flags, (size_t)count * 2 * sizeof(int))) != hipSuccess ||
+      (e = hipHostMalloc((void **)&b->h_flags, (size_t)count * 3 * sizeof(int))) != hipSuccess ||
       (e = hipHostMalloc((void **)&b->h_diff, count * sizeof(double))) != hipSuccess ||
       (e = hipHostMalloc((void **)&b->h_norm, count * sizeof(double))) != hipSuccess) {
     pgf_batch_destroy(b);
@@ -993,7 +994,7 @@ int pgf_batch_create(const pgf_handle *handles, int count, pgf_batch *out) {
   if ((e = hipMemcpy(b->tab, tab.data(), count * sizeof(BInst), hipMemcpyHostToDevice)) !=
           hipSuccess ||
       (e = hipMemset(b->ctl, 0, (size_t)count * 4 * sizeof(int))) != hipSuccess ||
-      (e = hipMemset(b->flags_out, 0, (size_t)count * 2 * sizeof(int))) != hipSuccess) {
+      (e = hipMemset(b->flags_out, 0, (size_t)count * 3 * sizeof(int))) != hipSuccess) {
     pgf_batch_destroy(b);
     return PGF_HIP_ERROR + (int)e;
   }
@@ -1010,6 +1011,11 @@ int pgf_batch_destroy(pgf_batch b) {
     if (p) (void)hipFree(p);
   for (void *p : {(void *)b->h_flags, (void *)b->h_diff, (void *)b->h_norm})
     if (p) (void)hipHostFree(p);
+  for (hipEvent_t e : b->prof.pool) (void)hipEventDestroy(e);
+  for (auto &sp : b->prof.update_spans) {
+    (void)hipEventDestroy(sp.first);
+    (void)hipEventDestroy(sp.second);
+  }
   if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
   return PGF_OK;
@@ -1100,13 +1106,15 @@ int pgf_batch_step_async(pgf_batch b, unsigned policy, double tau) {
   // kernels of instances whose factor is still valid return at once (ctl[0] == 0); when the
   // host knows that every instance refactorises (Full) or none does, skip the other half
   const bool none_factor = !recompute && b->all_factored;
-  if (!none_factor) ldlt_batch_factor_async(b->stream, b->tab, b->B, Nmax, b->m, b->OB);
+  if (!none_factor)
+    ldlt_batch_factor_async(b->stream, b->tab, b->B, Nmax, b->m, b->OB,
+                            b->prof.enabled ? &b->prof : nullptr);
   ldlt_batch_solve_async(b->stream, b->tab, b->B, Nmax, b->m, !force);
   batch_launch_step_update(b->stream, b->tab, b->B, b->sc, b->diff_out, b->flags_out);
   b->eval_fresh = false;
   BHIPCHK(b, hipMemcpyAsync(b->h_diff, b->diff_out, b->B * sizeof(double), hipMemcpyDeviceToHost,
                             b->stream));
-  BHIPCHK(b, hipMemcpyAsync(b->h_flags, b->flags_out, (size_t)b->B * 2 * sizeof(int),
+  BHIPCHK(b, hipMemcpyAsync(b->h_flags, b->flags_out, (size_t)b->B * 3 * sizeof(int),
                             hipMemcpyDeviceToHost, b->stream));
   b->step_pending = true;
   return PGF_OK;
@@ -1120,13 +1128,49 @@ int pgf_batch_sync(pgf_batch b, int *status, int *n_neg, double *diff) {
   BHIPCHK(b, hipStreamSynchronize(b->stream));
   bool all_ok = true;
   for (int i = 0; i < b->B; ++i) {
-    const bool bad = b->h_flags[2 * i] != 0;
+    const bool bad = b->h_flags[3 * i] != 0;
     all_ok = all_ok && !bad;
     if (status) status[i] = bad ? PGF_SINGULAR : PGF_OK;
-    if (n_neg) n_neg[i] = b->h_flags[2 * i + 1];
+    if (n_neg) n_neg[i] = b->h_flags[3 * i + 1];
     if (diff) diff[i] = b->h_diff[i];
   }
   b->all_factored = all_ok;
+  return PGF_OK;
+}
+
+int pgf_batch_profile_enable(pgf_batch b, int on) {
+  if (!b) return PGF_INVALID;
+  b->prof.enabled = on != 0;
+  return PGF_OK;
+}
+
+// Accumulated device time of the K = OB trailing-update launches since the last call and
+// their algorithmic flops, from the reduced sizes of the last synchronised step.
+int pgf_batch_profile_read(pgf_batch b, double *update_ms, int64_t *update_launches,
+                           double *update_flops) {
+  if (!b) return PGF_INVALID;
+  if (b->step_pending) return bfail(b, PGF_NOT_READY, "pgf_batch_sync the previous step first");
+  (void)hipSetDevice(b->device);
+  BHIPCHK(b, hipStreamSynchronize(b->stream));
+  PgfProfile &p = b->prof;
+  double ms_sum = 0.0, fl_sum = 0.0;
+  for (size_t i = 0; i < p.update_spans.size(); ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.update_spans[i].first, p.update_spans[i].second) == hipSuccess)
+      ms_sum += ms;
+    const double start = p.update_flops[i];
+    for (int k = 0; k < b->B; ++k) {
+      const double T = (double)(b->h_flags[3 * k + 2] + b->m) - start;
+      if (T > 0) fl_sum += 2.0 * b->OB * (0.5 * T * (T + 1.0) + T);
+    }
+    p.pool.push_back(p.update_spans[i].first);
+    p.pool.push_back(p.update_spans[i].second);
+  }
+  if (update_ms) *update_ms = ms_sum;
+  if (update_launches) *update_launches = (int64_t)p.update_spans.size();
+  if (update_flops) *update_flops = fl_sum;
+  p.update_spans.clear();
+  p.update_flops.clear();
   return PGF_OK;
 }
 

@@ -92,12 +92,14 @@ void batch_launch_eval(hipStream_t s, const BInst *tab, int B, const BatchScalar
 void batch_launch_mask(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc, int mode,
                        int use_tau, double f_x, double f_x0, double f_d);
 void batch_launch_rhs_assemble(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc);
+// flags_out: [3 i] zero-pivot flag, [3 i + 1] negative pivots, [3 i + 2] |I| of instance i
 void batch_launch_step_update(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc,
                               double *diff_out, int *flags_out);
 void batch_launch_res_norm(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc,
                            double *norm_out);
 // pgf_ldlt.hip
-void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m, int OB);
+void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m, int OB,
+                             PgfProfile *prof);
 void ldlt_batch_solve_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m,
                             bool any_unfactored_solve);
 

@@ -656,8 +656,9 @@ __global__ __launch_bounds__(256) void kb_step_final(const BInst *__restrict__ t
   const BInst &I = tab[blockIdx.z];
   b_final_reduce(I.red, nb, diff_out + blockIdx.z, 1);
   if (threadIdx.x == 0) {
-    flags_out[2 * blockIdx.z] = I.flags[0];
-    flags_out[2 * blockIdx.z + 1] = I.flags[1];
+    flags_out[3 * blockIdx.z] = I.flags[0];
+    flags_out[3 * blockIdx.z + 1] = I.flags[1];
+    flags_out[3 * blockIdx.z + 2] = I.counts[0];
     if (I.ctl[0]) I.ctl[1] = (I.flags[0] == 0) ? 1 : 0;
   }
 }

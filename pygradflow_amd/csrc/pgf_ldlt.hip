@@ -1754,7 +1754,8 @@ hipError_t ldlt_solve_async(DenseLdlt &f, const double *rhs, double *sol) {
 }
 
 // ------------------------------------------------------------------ batched host schedule
-void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m, int OB) {
+void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m, int OB,
+                             PgfProfile *p) {
   if (Nmax <= 0 || B <= 0) return;
   // PGF_BATCH_LL=0: the single-instance schedule with a batch dimension (fused panel
   // kernel + K = 64 inner updates); default: the left-looking split panel step
@@ -1782,8 +1783,19 @@ void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, i
     }
     if (obEnd < Nmax) {
       const int tr = (Nmax + 1 - obEnd + 63) / 64, tc = (Nmax - obEnd + 63) / 64;
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (p) {
+        e0 = prof_event(p);
+        e1 = prof_event(p);
+        (void)hipEventRecord(e0, s);
+      }
       hipLaunchKernelGGL(kb_ldlt_update, dim3(batch_grid(B, tc * tr)), dim3(256), 0, s, tab, B, tc,
                          tr, m, (int64_t)OB, buf, 0, obEnd, obEnd, 0x7fffffff, ob0, OB);
+      if (p) {
+        (void)hipEventRecord(e1, s);
+        p->update_spans.emplace_back(e0, e1);
+        p->update_flops.push_back((double)obEnd);  // region start; flops need the N_i (sync)
+      }
     }
   }
   if (!ll)
