@@ -3,7 +3,8 @@
 ``HipStepSolver`` / ``HipLinearSolver`` are the StepSolver / LinearSolver pair
 (``Params(step_solver=HipStepSolver)``); ``newton_method`` mirrors the reference's
 policy factory; ``DeviceNewton`` is the HBM-resident driver for linear-quadratic
-problems.  All arithmetic is in ``libpgf_hip.so`` (C ABI: ``include/pgf_hip.h``);
+problems, ``BatchedDeviceNewton`` its many-instance form; ``DistanceRatioController`` is the
+reference's default step controller on top of either.  All arithmetic is in ``libpgf_hip.so`` (C ABI: ``include/pgf_hip.h``);
 there is no CPU fallback.
 """
 
@@ -34,4 +35,13 @@ def __getattr__(name):
         from . import newton
 
         return getattr(newton, name)
+    if name in ("DistanceRatioController", "DeviceDistanceRatioController", "NewtonController",
+                "StepController", "StepControlResult", "gradient_flow"):
+        from . import step_control
+
+        return getattr(step_control, name)
+    if name == "BatchedDeviceNewton":
+        from .batched import BatchedDeviceNewton
+
+        return BatchedDeviceNewton
     raise AttributeError(name)

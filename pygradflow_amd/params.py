@@ -70,6 +70,16 @@ class Params:
     active_set_tau: Optional[float] = None
     report_rcond: bool = False
     inertia_correction: bool = False
+    # step-size control (reference params.py:206-217)
+    theta_max: float = 0.9
+    theta_ref: float = 0.5
+    lamb_init: float = 1.0
+    lamb_min: float = 1e-12
+    lamb_max: float = 1e12
+    lamb_inc: float = 2.0
+    lamb_red: float = 0.5
+    K_P: float = 0.2
+    K_I: float = 0.005
 
     def __post_init__(self):
         for key, typ in (

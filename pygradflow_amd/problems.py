@@ -152,6 +152,36 @@ class QuarticProblem(_ProblemShape):
 # --------------------------------------------------------------------------
 
 
+class RosenbrockProblem(_ProblemShape):
+    """f(x) = (a - x_0)^2 + b (x_1 - x_0^2)^2, no constraints, no bounds: BASELINE config 1's
+    problem (the reference's docs/rosenbrock.py), written out from the formula."""
+
+    pgf_constant_derivs = False
+
+    def __init__(self, a=1.0, b=100.0):
+        super().__init__(np.full(2, -np.inf), np.full(2, np.inf), 0)
+        self.a, self.b = float(a), float(b)
+
+    def obj(self, x):
+        return (self.a - x[0]) ** 2 + self.b * (x[1] - x[0] ** 2) ** 2
+
+    def obj_grad(self, x):
+        r = x[1] - x[0] ** 2
+        return np.array([-2.0 * (self.a - x[0]) - 4.0 * self.b * x[0] * r, 2.0 * self.b * r])
+
+    def cons(self, x):
+        return np.zeros(0)
+
+    def cons_jac(self, x):
+        return sps.csr_matrix((0, 2))
+
+    def lag_hess(self, x, y):
+        r = x[1] - x[0] ** 2
+        h00 = 2.0 - 4.0 * self.b * r + 8.0 * self.b * x[0] ** 2
+        h01 = -4.0 * self.b * x[0]
+        return sps.csr_matrix(np.array([[h00, h01], [h01, 2.0 * self.b]]))
+
+
 def dense_qp(n=4096, m=1024, seed=0, boxed_frac=0.0, box=0.01) -> LinearQuadraticProblem:
     """BASELINE config 2 (and, with seeds 0..255 and n=1024/m=256, config 4):
     ``G~N(0,1)/sqrt(n)``, ``Q=GG'+I``, ``A~N(0,1)/sqrt(n)``; bounds +-inf.

@@ -1,0 +1,238 @@
+"""Newton-based step controllers: the immediate caller of the hot path.
+
+Host-side mirror of the reference's controller surface with the same names and decisions:
+
+* ``StepControlResult`` / ``StepController.compute_step``  (``step/step_control.py:19-107``):
+  a ``StepSolverError`` inside a step becomes "rejected, lambda <- 2 lambda";
+* ``NewtonController.newton_steps / tau_vals / compute_tau`` (``step/newton_control.py:13-88``);
+* ``DistanceRatioController.step``  (``step/distance_ratio_control.py:12-78``): two Newton
+  steps per outer iteration, theta = ||d_2|| / ||d_1||, accept iff theta <= theta_max,
+  PI update of lambda on the log scale, early exit when the unscaled residual
+  ``||F(z_1)||`` (``ImplicitFunc.value_at``, ``implicit_func.py:150-161``) is below
+  ``newton_tol``.
+
+Two drivers share that decision logic: ``DistanceRatioController`` works on host iterates
+through ``newton_method`` (the plugin path, any problem), ``DeviceDistanceRatioController``
+keeps a linear-quadratic problem's point in HBM (``DeviceNewton``) and reads back only the
+two step lengths and one residual norm per outer iteration.
+"""
+
+from __future__ import annotations
+
+import abc
+
+import numpy as np
+
+from .controller import ControllerSettings, LogController
+from .errors import StepSolverError
+from .newton import newton_method
+from .params import enum_name
+
+ACTIVE_EPS = 1e-8  # implicit_func.py:44
+
+
+class StepControlResult:
+    def __init__(self, iterate, lamb, active_set, rcond, accepted):
+        self.iterate = iterate
+        self.lamb = lamb
+        self.active_set = active_set
+        self.rcond = rcond
+        self.accepted = accepted
+
+    @staticmethod
+    def from_step_result(step_result, lamb, accepted):
+        return StepControlResult(step_result.iterate, lamb, step_result.active_set,
+                                 step_result.rcond, accepted)
+
+
+def implicit_residual(problem, orig_iterate, dt, iterate, rho):
+    """Unscaled implicit-Euler residual ``F(z; z^)`` with its own active set
+    (``ImplicitFunc.value_at`` with ``active_set=None``, implicit_func.py:131-161)."""
+    lb, ub = problem.var_lb, problem.var_ub
+    p = orig_iterate.x - dt * iterate.aug_lag_deriv_x(rho)
+    active = np.logical_or(p < lb - ACTIVE_EPS, p > ub + ACTIVE_EPS)
+    proj = np.copy(p)
+    proj[active] = np.clip(p[active], lb[active], ub[active])
+    xval = iterate.x - proj
+    yval = iterate.y - (orig_iterate.y + dt * iterate.aug_lag_deriv_y())
+    return np.concatenate([xval, yval])
+
+
+class StepController(abc.ABC):
+    def __init__(self, problem, params):
+        self.problem = problem
+        self.params = params
+        self.lamb = params.lamb_init
+
+    @abc.abstractmethod
+    def step(self, iterate, rho, dt, display=False, timer=None) -> StepControlResult:
+        raise NotImplementedError()
+
+    def update_stepsize_after_fail(self, lamb):
+        return 2.0 * lamb
+
+    def compute_step(self, iterate, rho, dt, display=False, timer=None) -> StepControlResult:
+        """``step`` with linear-algebra failures turned into a rejected step at half the
+        step size (step_control.py:69-107)."""
+        try:
+            result = self.step(iterate, rho, dt, display, timer)
+            if result.accepted and hasattr(result.iterate, "check_eval"):
+                result.iterate.check_eval()
+            return result
+        except StepSolverError:
+            lamb = self.update_stepsize_after_fail(1.0 / dt)
+            return StepControlResult(iterate, lamb, None, None, False)
+
+
+class NewtonController(StepController):
+    def newton_steps(self, orig_iterate, rho, dt):
+        tau = self.compute_tau(orig_iterate, rho)
+        self.method = newton_method(self.problem, self.params, orig_iterate, dt, rho, tau)
+        curr = orig_iterate
+        while True:
+            nxt = self.method.step(curr)
+            yield nxt
+            curr = nxt.iterate
+
+    def tau_vals(self, initial_iterate, rho):
+        """Per variable: the step length along -g at which its bound is reached, -1 where the
+        gradient entry is (numerically) zero (newton_control.py:40-59)."""
+        x = initial_iterate.x
+        g = initial_iterate.aug_lag_deriv_x(rho)
+        lb, ub = self.problem.var_lb, self.problem.var_ub
+        moving = np.logical_not(np.isclose(g, 0.0))
+        down = np.logical_and(g > 0.0, moving)
+        up = np.logical_and(g < 0.0, moving)
+        vals = np.full_like(x, fill_value=-1)
+        vals[down] = (x[down] - lb[down]) / g[down]
+        vals[up] = (ub[up] - x[up]) / -g[up]
+        return vals
+
+    def compute_tau(self, initial_iterate, rho):
+        params = self.params
+        kind = enum_name(params.active_set_type)
+        method = params.active_set_method
+        if kind == "Explicit":
+            assert params.active_set_tau is not None and method is None
+            return params.active_set_tau
+        assert params.active_set_tau is None
+        if method is not None:
+            return method(initial_iterate, self.lamb, rho)
+        if kind == "Standard":
+            return None
+        vals = self.tau_vals(initial_iterate, rho)
+        if kind == "SmallestActiveSet":
+            if (vals <= 0).all():
+                return 1.0
+            return 0.5 * np.min(vals[vals > 0])
+        return max(np.max(vals), 1.0)
+
+
+def _ratio_decision(ctl, params, lamb, first_diff, second_diff):
+    """theta-test and PI update shared by both drivers -> (lamb_n, accepted)."""
+    theta = second_diff / first_diff
+    accepted = theta <= params.theta_max
+    if accepted:
+        lamb_n = max(params.lamb_min, lamb / ctl.update(theta))
+    else:
+        lamb_n = lamb * params.lamb_inc
+        if ctl.error_sum > 0.0:
+            ctl.reset()
+    return lamb_n, accepted
+
+
+class DistanceRatioController(NewtonController):
+    def __init__(self, problem, params):
+        super().__init__(problem, params)
+        self.controller = LogController(ControllerSettings.from_params(params), params.theta_ref)
+
+    def step(self, iterate, rho, dt, display=False, timer=None):
+        assert dt > 0.0
+        lamb = 1.0 / dt
+        params = self.params
+        steps = self.newton_steps(iterate, rho, dt)
+        mid = next(steps)
+        mid_norm = np.linalg.norm(implicit_residual(self.problem, iterate, dt, mid.iterate, rho))
+        if mid_norm <= params.newton_tol:
+            lamb_n = max(lamb * params.lamb_red, params.lamb_min)
+            return StepControlResult.from_step_result(mid, lamb_n, True)
+        first = mid.diff
+        if first == 0.0:
+            return StepControlResult.from_step_result(mid, lamb, True)
+        final = next(steps)
+        second = final.diff
+        if second == 0.0:
+            return StepControlResult.from_step_result(final, lamb, True)
+        lamb_n, accepted = _ratio_decision(self.controller, params, lamb, first, second)
+        self.lamb = lamb_n
+        return StepControlResult.from_step_result(final, lamb_n, accepted)
+
+
+class DeviceControlResult:
+    """Outcome of one device-resident outer iteration (the point stays in HBM)."""
+
+    def __init__(self, lamb, accepted, newton_steps, diffs, residual_norm):
+        self.lamb = lamb
+        self.accepted = accepted
+        self.newton_steps = newton_steps
+        self.diffs = diffs
+        self.residual_norm = residual_norm
+
+
+class DeviceDistanceRatioController:
+    """``DistanceRatioController`` for a ``DeviceNewton`` (linear-quadratic problem in HBM).
+
+    ``step(rho, dt)`` starts an outer step at the current device point, runs one or two
+    Newton steps on device and applies the same decisions; on rejection (or a failed
+    factorisation) the device point is put back to the outer point.  Per outer iteration
+    the host reads two step lengths and one residual norm.
+    """
+
+    def __init__(self, device_newton, params):
+        self.dn = device_newton
+        self.params = params
+        self.lamb = params.lamb_init
+        self.controller = LogController(ControllerSettings.from_params(params), params.theta_ref)
+
+    def step(self, rho, dt):
+        assert dt > 0.0
+        dn, params = self.dn, self.params
+        lamb = 1.0 / dt
+        x_hat, y_hat = dn.point()  # a rejected step returns to the outer point
+        dn.advance_outer(dt, rho)
+        try:
+            first, _ = dn.step()
+            mid_norm = dn.residual_norm()
+            if mid_norm <= params.newton_tol:
+                return DeviceControlResult(max(lamb * params.lamb_red, params.lamb_min), True, 1,
+                                           (first,), mid_norm)
+            if first == 0.0:
+                return DeviceControlResult(lamb, True, 1, (first,), mid_norm)
+            second, _ = dn.step()
+        except StepSolverError:
+            dn.set_point(x_hat, y_hat)
+            return DeviceControlResult(2.0 * lamb, False, 0, (), None)
+        if second == 0.0:
+            return DeviceControlResult(lamb, True, 2, (first, second), mid_norm)
+        lamb_n, accepted = _ratio_decision(self.controller, params, lamb, first, second)
+        self.lamb = lamb_n
+        if not accepted:
+            dn.set_point(x_hat, y_hat)
+        return DeviceControlResult(lamb_n, accepted, 2, (first, second), mid_norm)
+
+
+def gradient_flow(controller, make_iterate, x0, y0, rho, iterations, lamb=None):
+    """Minimal outer loop around a host step controller (the accept / lambda bookkeeping of
+    ``Solver.solve``, solver.py:300-378, without penalty updates and termination tests).
+    Returns the per-iteration records ``(lamb_used, accepted, x, y)``."""
+    iterate = make_iterate(np.asarray(x0, dtype=np.float64), np.asarray(y0, dtype=np.float64))
+    lamb = controller.params.lamb_init if lamb is None else lamb
+    records = []
+    for _ in range(iterations):
+        res = controller.compute_step(iterate, rho, 1.0 / lamb, False, None)
+        if res.accepted:
+            iterate = res.iterate
+        records.append(dict(lamb=lamb, lamb_next=res.lamb, accepted=bool(res.accepted),
+                            x=np.array(iterate.x), y=np.array(iterate.y)))
+        lamb = res.lamb
+    return records

@@ -14,8 +14,13 @@ def case_names():
     return sorted(
         os.path.basename(p)[:-4]
         for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
-        if not p.endswith("linear_solver_5x5.npz") and not os.path.basename(p).startswith("extras_")
+        if not p.endswith("linear_solver_5x5.npz")
+        and not os.path.basename(p).startswith(("extras_", "ctl_"))
     )
+
+
+def controller_case_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "ctl_*.npz")))
 
 
 def load_case(name):
@@ -41,6 +46,8 @@ def rebuild_problem(case):
         return P.LinearQuadraticProblem(
             case["problem/Q"], case["problem/q"], case["problem/A"], case["problem/b"], lb, ub
         )
+    if kind == "rosenbrock":
+        return P.RosenbrockProblem(float(case["problem/a"]), float(case["problem/b"]))
     assert kind == "quartic"
     return P.QuarticProblem(
         case["problem/Q"], case["problem/q"], case["problem/a"], case["problem/A"],

@@ -1,0 +1,168 @@
+"""Step controllers against trajectories recorded from the reference's
+DistanceRatioController (tools/gen_golden.py, ctl_*.npz) and the reference's own controller
+tests (tests/pygradflow/test_controller.py).  CPU tests run the host logic over the oracle
+step solver; the GPU tests run the same logic over the HIP step solver and the
+device-resident driver."""
+
+import math
+
+import numpy as np
+import pytest
+
+from tests import golden_util as G
+from tests.oracle_step_solver import OracleStepSolver
+
+from pygradflow_amd.controller import Controller, ControllerSettings, LogController
+from pygradflow_amd.iterate import Iterate
+from pygradflow_amd.params import Params
+from pygradflow_amd import step_control as SC
+
+
+# ---- reference tests/pygradflow/test_controller.py, restated ------------------------------
+@pytest.fixture
+def settings():
+    return ControllerSettings(K_P=1e-1, K_I=0.0, lamb_init=0.0, lamb_red=0.5)
+
+
+@pytest.mark.parametrize("val", [0.0, 1.0, 2.0])
+def test_controller_sign_and_convergence(settings, val):
+    ctl = Controller(settings, 1.0)
+    u = ctl.update(val)
+    assert (u < 0.0) if val > 1.0 else (u == 0.0 if val == 1.0 else u > 0.0)
+    ctl = Controller(settings, 1.0)
+    for _ in range(100):
+        val = val + ctl.update(val)  # control x' = u
+    assert np.allclose(val, 1.0, atol=1e-2)
+
+
+@pytest.mark.parametrize("val", [1e-1, 1e0, 1e1])
+def test_log_controller_sign_and_convergence(settings, val):
+    u = math.log(LogController(settings, 1.0).update(val))
+    assert (u < 0.0) if val > 1.0 else (u == 0.0 if val == 1.0 else u > 0.0)
+    ctl = LogController(settings, 1.0)
+    for _ in range(200):
+        val = val * ctl.update(val)
+    assert np.allclose(val, 1.0, atol=1e-2)
+
+
+def test_pi_law_values():
+    ctl = Controller(ControllerSettings(K_P=0.2, K_I=0.005, lamb_init=1.0, lamb_red=0.5), 0.5)
+    assert ctl.value == 1.0
+    assert ctl.update(0.3) == pytest.approx(0.2 * 0.2 + 0.005 * 0.2)
+    assert ctl.update(0.9) == pytest.approx(0.2 * -0.4 + 0.005 * (0.2 - 0.4))
+    ctl.reset()
+    assert ctl.error_sum == 0.0
+
+
+# ---- tau selection (newton_control.py:40-88) ----------------------------------------------
+def _tiny_problem():
+    from pygradflow_amd import problems as P
+
+    Q = np.eye(3)
+    q = np.array([1.0, -2.0, 0.0])
+    return P.LinearQuadraticProblem(Q, q, np.zeros((0, 3)), np.zeros(0),
+                                    np.array([-1.0, -1.0, -1.0]), np.array([1.0, 3.0, 1.0]))
+
+
+def test_tau_vals_and_compute_tau():
+    prob = _tiny_problem()
+    it = Iterate(prob, Params(), np.zeros(3), np.zeros(0))
+    ctl = SC.DistanceRatioController(prob, Params())
+    # g = q at x = 0: variable 0 moves down to lb (distance 1 / 1), variable 1 up to ub
+    # (distance 3 / 2), variable 2 does not move
+    assert np.array_equal(ctl.tau_vals(it, 1.0), np.array([1.0, 1.5, -1.0]))
+    assert ctl.compute_tau(it, 1.0) is None
+    small = SC.DistanceRatioController(prob, Params(active_set_type="SmallestActiveSet"))
+    assert small.compute_tau(it, 1.0) == 0.5
+    large = SC.DistanceRatioController(prob, Params(active_set_type="LargestActiveSet"))
+    assert large.compute_tau(it, 1.0) == 1.5
+    expl = SC.DistanceRatioController(prob, Params(active_set_type="Explicit", active_set_tau=0.25))
+    assert expl.compute_tau(it, 1.0) == 0.25
+    hook = SC.DistanceRatioController(prob, Params(active_set_method=lambda it, lamb, rho: 7.0))
+    assert hook.compute_tau(it, 1.0) == 7.0
+
+
+def test_implicit_residual_matches_oracle():
+    from oracle import newton_oracle as O
+    from pygradflow_amd import problems as P
+
+    prob = P.quartic_nlp(12, 4, seed=5)
+    rng = np.random.default_rng(0)
+    par = Params()
+    xh, yh = np.clip(rng.standard_normal(12), prob.var_lb, prob.var_ub), rng.standard_normal(4)
+    x, y = np.clip(xh + 0.3 * rng.standard_normal(12), prob.var_lb, prob.var_ub), yh + 0.1
+    orig, it = Iterate(prob, par, xh, yh), Iterate(prob, par, x, y)
+    mine = SC.implicit_residual(prob, orig, 0.4, it, 0.7)
+    ref = O.unscaled_residual(0.4, xh, yh, x, y, it.aug_lag_deriv_x(0.7), it.cons, prob.var_lb,
+                              prob.var_ub)
+    assert np.array_equal(mine, ref)
+
+
+def test_failed_step_doubles_lambda():
+    from pygradflow_amd.errors import StepSolverError
+
+    prob = _tiny_problem()
+
+    class Boom(SC.NewtonController):
+        def step(self, iterate, rho, dt, display=False, timer=None):
+            raise StepSolverError("singular")
+
+    it = Iterate(prob, Params(), np.zeros(3), np.zeros(0))
+    res = Boom(prob, Params()).compute_step(it, 1.0, 0.25)
+    assert not res.accepted and res.lamb == 8.0 and res.iterate is it and res.active_set is None
+
+
+# ---- trajectories recorded from the reference ---------------------------------------------
+def _run_host(case, name, step_solver):
+    prob = G.rebuild_problem(case)
+    nt = name.rsplit("_", 1)[1]
+    par = Params(newton_type=nt, step_solver=step_solver, lamb_init=float(case["lamb_init"]))
+    ctl = SC.DistanceRatioController(prob, par)
+    return SC.gradient_flow(ctl, lambda x, y: Iterate(prob, par, x, y), case["x0"], case["y0"],
+                            float(case["rho"]), int(case["iterations"]))
+
+
+def _check(recs, case, tol):
+    for k, r in enumerate(recs):
+        assert r["accepted"] == bool(case["accepted"][k]), k
+        assert r["lamb"] == pytest.approx(float(case["lamb"][k]), rel=tol), k
+        assert r["lamb_next"] == pytest.approx(float(case["lamb_next"][k]), rel=tol), k
+        assert G.rel_err(r["x"], case["x"][k]) <= tol, k
+        assert G.rel_err(r["y"], case["y"][k]) <= tol, k
+
+
+@pytest.mark.parametrize("name", G.controller_case_names())
+def test_distance_ratio_controller_host_logic(name):
+    case = G.load_case(name)
+    _check(_run_host(case, name, OracleStepSolver), case, 1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", G.controller_case_names())
+def test_distance_ratio_controller_hip(pgf, name):
+    """Same trajectories with the HIP step solver behind the plugin hook."""
+    case = G.load_case(name)
+    _check(_run_host(case, name, pgf.HipStepSolver), case, 1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", [n for n in G.controller_case_names() if "dense_qp" in n])
+def test_device_distance_ratio_controller(pgf, name):
+    """Device-resident outer loop: point, H, J in HBM; the host sees two step lengths and one
+    residual norm per outer iteration."""
+    case = G.load_case(name)
+    prob = G.rebuild_problem(case)
+    nt = name.rsplit("_", 1)[1]
+    par = Params(newton_type=nt, lamb_init=float(case["lamb_init"]))
+    dn = pgf.DeviceNewton(prob, nt, case["x0"], case["y0"], 1.0 / par.lamb_init, float(case["rho"]))
+    ctl = SC.DeviceDistanceRatioController(dn, par)
+    lamb = par.lamb_init
+    for k in range(int(case["iterations"])):
+        assert lamb == pytest.approx(float(case["lamb"][k]), rel=1e-8), k
+        res = ctl.step(float(case["rho"]), 1.0 / lamb)
+        assert res.accepted == bool(case["accepted"][k]), k
+        assert res.lamb == pytest.approx(float(case["lamb_next"][k]), rel=1e-8), k
+        x, y = dn.point()
+        assert G.rel_err(x, case["x"][k]) <= 1e-8 and G.rel_err(y, case["y"][k]) <= 1e-8, k
+        lamb = res.lamb
+    dn.close()

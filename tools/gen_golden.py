@@ -23,6 +23,7 @@ REF = os.environ.get("PGF_REFERENCE", "/root/reference")
 sys.dont_write_bytecode = True
 sys.path.insert(0, REF)
 sys.path.insert(0, REPO)
+sys.path.append(os.path.join(REPO, "tools", "_stubs"))  # cosmetic termcolor stand-in
 
 from pygradflow.iterate import Iterate  # noqa: E402  (reference)
 from pygradflow.newton import newton_method  # noqa: E402
@@ -154,6 +155,43 @@ def run_extras(name, problem, x0, y0, dt, rho, steps, store_problem, glob_steps=
     print(f"{name}: extras written (rcond {out['rcond/0']:.3e})")
 
 
+def run_controller_case(name, problem, x0, y0, rho, iterations, newton_type, store_problem,
+                        lamb_init=1.0):
+    """Outer iterations of the reference's DistanceRatioController
+    (step/distance_ratio_control.py:12-78) through StepController.compute_step, with the
+    accept / lambda bookkeeping of Solver.solve (solver.py:300-378) and nothing else."""
+    from pygradflow.step.distance_ratio_control import DistanceRatioController
+    from pygradflow.timer import Timer
+
+    params = Params(newton_type=getattr(NewtonType, newton_type), lamb_init=lamb_init)
+    ctl = DistanceRatioController(problem, params)
+    it = Iterate(problem, params, np.asarray(x0, float), np.asarray(y0, float))
+    lamb = params.lamb_init
+    rec = dict(lamb=[], lamb_next=[], accepted=[], x=[], y=[])
+    timer = Timer(1e9)
+    for _ in range(iterations):
+        res = ctl.compute_step(it, rho, 1.0 / lamb, False, timer)
+        if res.accepted:
+            it = res.iterate
+        rec["lamb"].append(lamb)
+        rec["lamb_next"].append(res.lamb)
+        rec["accepted"].append(bool(res.accepted))
+        rec["x"].append(np.array(it.x))
+        rec["y"].append(np.array(it.y))
+        lamb = res.lamb
+    out = dict(n=problem.num_vars, m=problem.num_cons, rho=rho, iterations=iterations,
+               lamb_init=lamb_init, x0=np.asarray(x0, float), y0=np.asarray(y0, float),
+               var_lb=problem.var_lb, var_ub=problem.var_ub,
+               lamb=np.array(rec["lamb"]), lamb_next=np.array(rec["lamb_next"]),
+               accepted=np.array(rec["accepted"]), x=np.array(rec["x"]),
+               y=np.array(rec["y"]).reshape(iterations, problem.num_cons))
+    out.update({"problem/" + k: v for k, v in (store_problem or {}).items()})
+    path = os.path.join(OUT, f"{name}_{newton_type}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}_{newton_type}: accepted {int(np.sum(rec['accepted']))}/{iterations}, "
+          f"lamb {rec['lamb'][0]:.3g} -> {rec['lamb_next'][-1]:.3g}")
+
+
 def qp_store(prob):
     return dict(kind="lq", Q=prob.hess_dense(), q=prob.q, A=prob.jac_dense(), b=prob.b)
 
@@ -185,8 +223,27 @@ def linear_solver_cases():
     print("linear_solver_5x5 written")
 
 
+def controller_cases():
+    """Step controllers: outer iterations of DistanceRatioController on
+    problems this repository can rebuild from the stored data (no reference fixture needed
+    at test time)."""
+    d2b = P.dense_qp(96, 24, seed=1, boxed_frac=0.25)
+    qn = P.quartic_nlp(12, 4, seed=3)
+    x0 = np.clip(np.zeros(12), qn.var_lb, qn.var_ub)
+    for nt in ("Simplified", "Full"):
+        run_controller_case("ctl_rosenbrock", P.RosenbrockProblem(), [0.0, 0.0], [], 1.0, 14, nt,
+                            dict(kind="rosenbrock", a=1.0, b=100.0))
+        run_controller_case("ctl_dense_qp_boxed_n96_m24", d2b, np.zeros(96), np.zeros(24), 1.0, 10,
+                            nt, qp_store(d2b))
+        run_controller_case("ctl_quartic_n12_m4", qn, x0, np.zeros(4), 0.7, 12, nt,
+                            quartic_store(qn))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--only-controllers" in sys.argv:
+        controller_cases()
+        return
     # the reference's own fixture problems, loaded by path (this repository has a `tests`
     # package of its own, which would shadow the reference's)
     import importlib.util
@@ -255,6 +312,7 @@ def main():
     run_extras("extras_dense_qp_boxed_n96_m24", d2b, np.zeros(96), np.zeros(24), 0.1, 1.0, 3,
                qp_store(d2b))
 
+    controller_cases()
     linear_solver_cases()
 
 
