@@ -21,3 +21,10 @@ def gpu_available():
     cnt = ctypes.c_int(0)
     rc = _lib.load().pgf_device_count(ctypes.byref(cnt))
     return rc == 0 and cnt.value > 0
+
+
+@pytest.fixture(scope="session")
+def pgf():
+    import pygradflow_amd as pgf
+
+    return pgf

@@ -15,13 +15,6 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-10
 
 
-@pytest.fixture(scope="module")
-def pgf():
-    import pygradflow_amd as pgf
-
-    return pgf
-
-
 def _sqd(rng, n1, n2, cond=1.0):
     """Symmetric quasi-definite test matrix [[A, B'],[B, -C]]."""
     G1 = rng.standard_normal((n1, n1)) / np.sqrt(max(n1, 1))
