@@ -122,11 +122,12 @@ def _run_host(case, name, step_solver):
                             float(case["rho"]), int(case["iterations"]))
 
 
-def _check(recs, case, tol):
+def _check(recs, case, tol, lamb_tol=None):
+    lamb_tol = tol if lamb_tol is None else lamb_tol
     for k, r in enumerate(recs):
         assert r["accepted"] == bool(case["accepted"][k]), k
-        assert r["lamb"] == pytest.approx(float(case["lamb"][k]), rel=tol), k
-        assert r["lamb_next"] == pytest.approx(float(case["lamb_next"][k]), rel=tol), k
+        assert r["lamb"] == pytest.approx(float(case["lamb"][k]), rel=lamb_tol), k
+        assert r["lamb_next"] == pytest.approx(float(case["lamb_next"][k]), rel=lamb_tol), k
         assert G.rel_err(r["x"], case["x"][k]) <= tol, k
         assert G.rel_err(r["y"], case["y"][k]) <= tol, k
 
@@ -140,9 +141,12 @@ def test_distance_ratio_controller_host_logic(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", G.controller_case_names())
 def test_distance_ratio_controller_hip(pgf, name):
-    """Same trajectories with the HIP step solver behind the plugin hook."""
+    """Same trajectories with the HIP step solver behind the plugin hook.  Iterates to 1e-8.
+    lambda only to 1e-5: once Newton has converged the second step length is a few ulps of
+    the iterate, theta = ||d_2|| / ||d_1|| is then known to ~1e-6 relative for ANY linear
+    solver other than the recording one, and d(lambda)/lambda = K_P d(theta)/theta."""
     case = G.load_case(name)
-    _check(_run_host(case, name, pgf.HipStepSolver), case, 1e-8)
+    _check(_run_host(case, name, pgf.HipStepSolver), case, 1e-8, lamb_tol=1e-5)
 
 
 @pytest.mark.gpu
@@ -158,10 +162,10 @@ def test_device_distance_ratio_controller(pgf, name):
     ctl = SC.DeviceDistanceRatioController(dn, par)
     lamb = par.lamb_init
     for k in range(int(case["iterations"])):
-        assert lamb == pytest.approx(float(case["lamb"][k]), rel=1e-8), k
+        assert lamb == pytest.approx(float(case["lamb"][k]), rel=1e-5), k
         res = ctl.step(float(case["rho"]), 1.0 / lamb)
         assert res.accepted == bool(case["accepted"][k]), k
-        assert res.lamb == pytest.approx(float(case["lamb_next"][k]), rel=1e-8), k
+        assert res.lamb == pytest.approx(float(case["lamb_next"][k]), rel=1e-5), k
         x, y = dn.point()
         assert G.rel_err(x, case["x"][k]) <= 1e-8 and G.rel_err(y, case["y"][k]) <= 1e-8, k
         lamb = res.lamb
