@@ -39,9 +39,13 @@ if __name__ == "__main__":
         hbm = (2.0 * fk + wk) * 1024.0
         out[k] = dict(launches=n, fetch_kib_raw=fk, write_kib=wk, hbm_bytes_per_launch=hbm)
         print(f"{k[:48]:48s} launches={n:5d} FETCH_SIZE={fk:12.1f} KiB (x2) WRITE_SIZE={wk:12.1f} KiB  -> {hbm/1e6:10.2f} MB/launch")
-    dom = next((k for k in out if "k_ldlt_update" in k), None)
-    if dom and len(sys.argv) > 3:
-        json.dump({"k_ldlt_update": dict(out[dom], kernel=dom,
-                                         note="(2*FETCH_SIZE + WRITE_SIZE) KiB averaged over all launches; "
-                                              "gfx950 FETCH_SIZE x2 correction; estimate")},
-                  open(sys.argv[3], "w"), indent=1)
+    if len(sys.argv) > 3:
+        rec = {}
+        for k in out:
+            if "ldlt_update" not in k:
+                continue
+            key = "kb_ldlt_update" if k.startswith("kb_") else "k_ldlt_update"
+            rec[key] = dict(out[k], kernel=k,
+                            note="(2*FETCH_SIZE + WRITE_SIZE) KiB averaged over all launches; "
+                                 "gfx950 FETCH_SIZE x2 correction; estimate")
+        json.dump(rec, open(sys.argv[3], "w"), indent=1)
