@@ -173,28 +173,39 @@ __device__ __forceinline__ void b_reduced_rhs(int n, int m, int nI, int nA, doub
 
 // ---------------------------------------------------------------- K assembly (a10, a12)
 // Lower triangle of K = [[H[I,I] + lamb I, .],[J[:,I], -delta I]] gathered from the
-// device-resident H, J.  blockIdx.y = row of K, lanes run along columns (coalesced
-// stores; loads coalesced whenever I is contiguous).
+// device-resident H, J.  A workgroup covers ASM_ROWS rows x 256 columns (lanes run along
+// columns: coalesced stores, loads coalesced whenever I is contiguous); the column's index
+// in H / J is looked up once per lane.  One row per workgroup was dispatch-bound in the
+// batched step (1.6 M workgroups).
+#define ASM_ROWS 8
 __device__ __forceinline__ void b_assemble_kkt(double *__restrict__ K, int64_t ldk,
-                                                      const double *__restrict__ H, int64_t ldh,
-                                                      const double *__restrict__ J, int64_t ldj,
-                                                      const int *__restrict__ idxI, int nI, int m,
-                                                      double lamb, double delta) {
-  const int i = blockIdx.y;
+                                               const double *__restrict__ H, int64_t ldh,
+                                               const double *__restrict__ J, int64_t ldj,
+                                               const int *__restrict__ idxI, int nI, int m,
+                                               double lamb, double delta) {
+  const int N = nI + m;
+  const int i0 = blockIdx.y * ASM_ROWS;
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j > i) return;
-  double v;
-  if (i < nI) {
-    v = H[(int64_t)idxI[i] * ldh + idxI[j]];
-    if (i == j) v = v + lamb;
-  } else {
-    const int r = i - nI;
-    if (j < nI)
-      v = J[(int64_t)r * ldj + idxI[j]];
-    else
-      v = (j == i) ? -delta : 0.0;
+  if (j >= N || j > i0 + ASM_ROWS - 1) return;
+  const int gj = (j < nI) ? idxI[j] : 0;
+#pragma unroll
+  for (int r = 0; r < ASM_ROWS; ++r) {
+    const int i = i0 + r;
+    if (i >= N) break;
+    if (j > i) continue;
+    double v;
+    if (i < nI) {
+      v = H[(int64_t)idxI[i] * ldh + gj];
+      if (i == j) v = v + lamb;
+    } else {
+      const int rr = i - nI;
+      if (j < nI)
+        v = J[(int64_t)rr * ldj + gj];
+      else
+        v = (j == i) ? -delta : 0.0;
+    }
+    K[(int64_t)i * ldk + j] = v;
   }
-  K[(int64_t)i * ldk + j] = v;
 }
 
 __device__ __forceinline__ void b_copy(double *__restrict__ dst, const double *__restrict__ src, int n) {
@@ -348,27 +359,41 @@ __device__ __forceinline__ void b_unscaled_res_sq(
 }
 
 // ---------------------------------------------------------------- single-instance kernels
-__global__ void k_scale_bounds(int n, double lamb, const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ slb, double *__restrict__ sub) {
+__global__ void k_scale_bounds(int n, double lamb, const double *__restrict__ lb,
+    const double *__restrict__ ub, double *__restrict__ slb, double *__restrict__ sub) {
   b_scale_bounds(n, lamb, lb, ub, slb, sub);
 }
 
-__global__ void k_active_set(int n, int use_tau, double lamb, double f_x, double f_x0, double f_d, const double *__restrict__ xhat, const double *__restrict__ x, const double *__restrict__ g, const double *__restrict__ slb, const double *__restrict__ sub, uint8_t *__restrict__ mask) {
+__global__ void k_active_set(int n, int use_tau, double lamb, double f_x, double f_x0, double f_d,
+    const double *__restrict__ xhat, const double *__restrict__ x, const double *__restrict__ g,
+    const double *__restrict__ slb, const double *__restrict__ sub, uint8_t *__restrict__ mask) {
   b_active_set(n, use_tau, lamb, f_x, f_x0, f_d, xhat, x, g, slb, sub, mask);
 }
 
-__global__ __launch_bounds__(1024) void k_compact(int n, const uint8_t *__restrict__ mask, int *__restrict__ idxI, int *__restrict__ idxA, int *__restrict__ pos, int *__restrict__ counts) {
+__global__ __launch_bounds__(1024) void k_compact(int n, const uint8_t *__restrict__ mask,
+    int *__restrict__ idxI, int *__restrict__ idxA, int *__restrict__ pos,
+    int *__restrict__ counts) {
   b_compact(n, mask, idxI, idxA, pos, counts);
 }
 
-__global__ void k_residual(int n, int m, double lamb, double dt, const double *__restrict__ xhat, const double *__restrict__ yhat, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ g, const double *__restrict__ c, const double *__restrict__ slb, const double *__restrict__ sub, const uint8_t *__restrict__ mask, double *__restrict__ F, double *__restrict__ b0full) {
+__global__ void k_residual(int n, int m, double lamb, double dt, const double *__restrict__ xhat,
+    const double *__restrict__ yhat, const double *__restrict__ x, const double *__restrict__ y,
+    const double *__restrict__ g, const double *__restrict__ c, const double *__restrict__ slb,
+    const double *__restrict__ sub, const uint8_t *__restrict__ mask, double *__restrict__ F,
+    double *__restrict__ b0full) {
   b_residual(n, m, lamb, dt, xhat, yhat, x, y, g, c, slb, sub, mask, F, b0full);
 }
 
-__global__ __launch_bounds__(256) void k_reduced_rhs(int n, int m, int nI, int nA, double fact, const double *__restrict__ F, const int *__restrict__ idxI, const double *__restrict__ H, int64_t ldh, const double *__restrict__ J, int64_t ldj, const double *__restrict__ b0full, double *__restrict__ rhs) {
+__global__ __launch_bounds__(256) void k_reduced_rhs(int n, int m, int nI, int nA, double fact,
+    const double *__restrict__ F, const int *__restrict__ idxI, const double *__restrict__ H,
+    int64_t ldh, const double *__restrict__ J, int64_t ldj, const double *__restrict__ b0full,
+    double *__restrict__ rhs) {
   b_reduced_rhs(n, m, nI, nA, fact, F, idxI, H, ldh, J, ldj, b0full, rhs);
 }
 
-__global__ __launch_bounds__(256) void k_assemble_kkt(double *__restrict__ K, int64_t ldk, const double *__restrict__ H, int64_t ldh, const double *__restrict__ J, int64_t ldj, const int *__restrict__ idxI, int nI, int m, double lamb, double delta) {
+__global__ __launch_bounds__(256) void k_assemble_kkt(double *__restrict__ K, int64_t ldk,
+    const double *__restrict__ H, int64_t ldh, const double *__restrict__ J, int64_t ldj,
+    const int *__restrict__ idxI, int nI, int m, double lamb, double delta) {
   b_assemble_kkt(K, ldk, H, ldh, J, ldj, idxI, nI, m, lamb, delta);
 }
 
@@ -380,35 +405,53 @@ __global__ void k_copy_u8(uint8_t *__restrict__ dst, const uint8_t *__restrict__
   b_copy_u8(dst, src, n);
 }
 
-__global__ void k_mask_diff(int n, const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, int *__restrict__ out) {
+__global__ void k_mask_diff(int n, const uint8_t *__restrict__ a, const uint8_t *__restrict__ b,
+    int *__restrict__ out) {
   b_mask_diff(n, a, b, out);
 }
 
-__global__ __launch_bounds__(256) void k_step_update(int n, int m, int nI, double fact, double rho, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ lb, const double *__restrict__ ub, const uint8_t *__restrict__ mask, const int *__restrict__ pos, const double *__restrict__ b0full, const double *__restrict__ F, const double *__restrict__ sol, double *__restrict__ dx, double *__restrict__ dy, double *__restrict__ xn, double *__restrict__ yn, double *__restrict__ red) {
+__global__ __launch_bounds__(256) void k_step_update(int n, int m, int nI, double fact,
+    double rho, const double *__restrict__ x, const double *__restrict__ y,
+    const double *__restrict__ lb, const double *__restrict__ ub,
+    const uint8_t *__restrict__ mask, const int *__restrict__ pos,
+    const double *__restrict__ b0full, const double *__restrict__ F,
+    const double *__restrict__ sol, double *__restrict__ dx, double *__restrict__ dy,
+    double *__restrict__ xn, double *__restrict__ yn, double *__restrict__ red) {
   b_step_update(n, m, nI, fact, rho, x, y, lb, ub, mask, pos, b0full, F, sol, dx, dy, xn, yn, red);
 }
 
-__global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__ red, int cnt, double *__restrict__ out, int take_sqrt) {
+__global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__ red, int cnt,
+    double *__restrict__ out, int take_sqrt) {
   b_final_reduce(red, cnt, out, take_sqrt);
 }
 
-__global__ __launch_bounds__(256) void k_gemv_rows(int rows, int cols, const double *__restrict__ M, int64_t ld, const double *__restrict__ v, const double *__restrict__ add, double sgn, double *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_gemv_rows(int rows, int cols,
+    const double *__restrict__ M, int64_t ld, const double *__restrict__ v,
+    const double *__restrict__ add, double sgn, double *__restrict__ out) {
   b_gemv_rows(rows, cols, M, ld, v, add, sgn, out);
 }
 
-__global__ __launch_bounds__(256) void k_gemvT_partial(int rows, int cols, const double *__restrict__ M, int64_t ld, const double *__restrict__ w, int chunk, double *__restrict__ partial) {
+__global__ __launch_bounds__(256) void k_gemvT_partial(int rows, int cols,
+    const double *__restrict__ M, int64_t ld, const double *__restrict__ w, int chunk,
+    double *__restrict__ partial) {
   b_gemvT_partial(rows, cols, M, ld, w, chunk, partial);
 }
 
-__global__ void k_sum_partials(int cols, int nparts, const double *__restrict__ partial, const double *__restrict__ base, double *__restrict__ out) {
+__global__ void k_sum_partials(int cols, int nparts, const double *__restrict__ partial,
+    const double *__restrict__ base, double *__restrict__ out) {
   b_sum_partials(cols, nparts, partial, base, out);
 }
 
-__global__ void k_mult_vec(int m, double rho, const double *__restrict__ c, const double *__restrict__ y, double *__restrict__ w) {
+__global__ void k_mult_vec(int m, double rho, const double *__restrict__ c,
+    const double *__restrict__ y, double *__restrict__ w) {
   b_mult_vec(m, rho, c, y, w);
 }
 
-__global__ __launch_bounds__(256) void k_unscaled_res_sq(int n, int m, double dt, const double *__restrict__ xhat, const double *__restrict__ yhat, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ g, const double *__restrict__ c, const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ red) {
+__global__ __launch_bounds__(256) void k_unscaled_res_sq(int n, int m, double dt,
+    const double *__restrict__ xhat, const double *__restrict__ yhat,
+    const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ g,
+    const double *__restrict__ c, const double *__restrict__ lb, const double *__restrict__ ub,
+    double *__restrict__ red) {
   b_unscaled_res_sq(n, m, dt, xhat, yhat, x, y, g, c, lb, ub, red);
 }
 
@@ -456,8 +499,8 @@ void launch_assemble_kkt(hipStream_t s, double *K, int64_t ldk, const double *H,
                          double lamb, double delta) {
   const int N = nI + m;
   if (N)
-    hipLaunchKernelGGL(k_assemble_kkt, dim3((N + 255) / 256, N), dim3(256), 0, s, K, ldk, H, ldh,
-                       J, ldj, idxI, nI, m, lamb, delta);
+    hipLaunchKernelGGL(k_assemble_kkt, dim3((N + 255) / 256, (N + ASM_ROWS - 1) / ASM_ROWS),
+                       dim3(256), 0, s, K, ldk, H, ldh, J, ldj, idxI, nI, m, lamb, delta);
 }
 
 void launch_copy(hipStream_t s, double *dst, const double *src, int n) {
@@ -626,13 +669,12 @@ __global__ __launch_bounds__(256) void kb_assemble(const BInst *__restrict__ tab
   const BInst &I = tab[blockIdx.z];
   if (I.ctl[0] == 0) return;
   const int nI = I.counts[0], N = nI + m;
-  const int i = blockIdx.y;
-  if (i > N) return;
-  if (i == 0 && blockIdx.x == 0 && threadIdx.x < 4) I.flags[threadIdx.x] = 0;
-  if (i == N) {
+  const int i0 = blockIdx.y * ASM_ROWS;
+  if (i0 > N) return;
+  if (i0 == 0 && blockIdx.x == 0 && threadIdx.x < 4) I.flags[threadIdx.x] = 0;
+  if (i0 <= N && N < i0 + ASM_ROWS) {  // this row block also holds row N: the rhs
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j < N) I.K[(int64_t)N * I.ldk + j] = I.rhs[j];
-    return;
   }
   b_assemble_kkt(I.K, I.ldk, I.H, I.ldh, I.J, I.ldj, I.idxI, nI, m, lamb, delta);
 }
@@ -713,8 +755,8 @@ void batch_launch_rhs_assemble(hipStream_t s, const BInst *tab, int B, const Bat
   if (!Nmax) return;
   hipLaunchKernelGGL(kb_residual, gb(Nmax, 256, B), dim3(256), 0, s, tab, n, m, sc.lamb, sc.dt);
   hipLaunchKernelGGL(kb_reduced_rhs, gb(Nmax, 4, B), dim3(256), 0, s, tab, n, m, sc.fact);
-  hipLaunchKernelGGL(kb_assemble, dim3((Nmax + 255) / 256, Nmax + 1, B), dim3(256), 0, s, tab, m,
-                     sc.lamb, sc.delta);
+  hipLaunchKernelGGL(kb_assemble, dim3((Nmax + 255) / 256, Nmax / ASM_ROWS + 1, B), dim3(256), 0,
+                     s, tab, m, sc.lamb, sc.delta);
 }
 
 void batch_launch_step_update(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc,
