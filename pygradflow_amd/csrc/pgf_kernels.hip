@@ -23,7 +23,8 @@ __device__ __forceinline__ void b_scale_bounds(int n, double lamb, const double 
 // ---------------------------------------------------------------- p and mask (a3, a4)
 // tau form: (f_x * x + f_x0 * x_hat) - f_d * g, evaluated left to right as numpy does
 // (implicit_func.py:237-244); plain form: lamb * x_hat - g (:246).
-__device__ __forceinline__ void b_active_set(int n, int use_tau, double lamb, double f_x, double f_x0, double f_d,
+__device__ __forceinline__ void b_active_set(int n, int use_tau, double lamb, double f_x,
+    double f_x0, double f_d,
                              const double *__restrict__ xhat, const double *__restrict__ x,
                              const double *__restrict__ g, const double *__restrict__ slb,
                              const double *__restrict__ sub, uint8_t *__restrict__ mask) {
@@ -93,7 +94,8 @@ __device__ __forceinline__ void b_compact(int n, const uint8_t *__restrict__ mas
 // ---------------------------------------------------------------- residual (a5, a6)
 // F = [lamb x - P(p) ; -(lamb y - (lamb y_hat + c))], P clips only masked entries
 // (np.clip == min(max(p, lo), hi)).  Also emits b0full = mask ? dt * F_x : 0 (a8).
-__device__ __forceinline__ void b_residual(int n, int m, double lamb, double dt, const double *__restrict__ xhat,
+__device__ __forceinline__ void b_residual(int n, int m, double lamb, double dt,
+    const double *__restrict__ xhat,
                            const double *__restrict__ yhat, const double *__restrict__ x,
                            const double *__restrict__ y, const double *__restrict__ g,
                            const double *__restrict__ c, const double *__restrict__ slb,
@@ -208,18 +210,21 @@ __device__ __forceinline__ void b_assemble_kkt(double *__restrict__ K, int64_t l
   }
 }
 
-__device__ __forceinline__ void b_copy(double *__restrict__ dst, const double *__restrict__ src, int n) {
+__device__ __forceinline__ void b_copy(double *__restrict__ dst, const double *__restrict__ src,
+    int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i];
 }
 
-__device__ __forceinline__ void b_copy_u8(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int n) {
+__device__ __forceinline__ void b_copy_u8(uint8_t *__restrict__ dst,
+    const uint8_t *__restrict__ src, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i];
 }
 
 // count positions where two masks differ (ActiveSet policy, newton.py:210)
-__device__ __forceinline__ void b_mask_diff(int n, const uint8_t *__restrict__ a, const uint8_t *__restrict__ b,
+__device__ __forceinline__ void b_mask_diff(int n, const uint8_t *__restrict__ a,
+    const uint8_t *__restrict__ b,
                             int *__restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool d = (i < n) && (a[i] != b[i]);
@@ -315,7 +320,8 @@ __device__ __forceinline__ void b_gemvT_partial(int rows, int cols,
 }
 
 // out[j] = base[j] + sum_rb partial[rb][j]
-__device__ __forceinline__ void b_sum_partials(int cols, int nparts, const double *__restrict__ partial,
+__device__ __forceinline__ void b_sum_partials(int cols, int nparts,
+    const double *__restrict__ partial,
                                const double *__restrict__ base, double *__restrict__ out) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= cols) return;
@@ -745,7 +751,8 @@ void batch_launch_eval(hipStream_t s, const BInst *tab, int B, const BatchScalar
 void batch_launch_mask(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc, int mode,
                        int use_tau, double f_x, double f_x0, double f_d) {
   if (mode != 0 && sc.n)
-    hipLaunchKernelGGL(kb_active_set, gb(sc.n, 256, B), dim3(256), 0, s, tab, sc.n, use_tau, sc.lamb,
+    hipLaunchKernelGGL(kb_active_set, gb(sc.n, 256, B), dim3(256), 0, s, tab, sc.n, use_tau,
+    sc.lamb,
                        f_x, f_x0, f_d);
   hipLaunchKernelGGL(kb_mask_adopt, dim3(1, 1, B), dim3(1024), 0, s, tab, sc.n, mode);
 }
