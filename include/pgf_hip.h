@@ -162,6 +162,11 @@ int pgf_qp_sync(pgf_handle h, int *n_neg, double *diff);
 /* ||F(z)||_2 of the UNSCALED residual (ImplicitFunc.value_at, implicit_func.py:150-161)
  * at the device point; host result, and optionally a device slot (RCCL all-gather input) */
 int pgf_qp_residual_norm(pgf_handle h, double *norm_out, double *norm_out_dev);
+/* Termination measures of the device point: out[0] = stat_res
+ * (iterate.py:174-177, with bounds_dual :140-152 and the ActiveSet of active_set.py:4-29 at
+ * tolerance active_tol), out[1] = cons_violation (:166-171), out[2] = bound_violation
+ * (:155-163), out[3] = ||y||_inf (DualNormUpdate, penalty.py:60-74). */
+int pgf_qp_measures(pgf_handle h, double active_tol, double *out);
 /* HIP stream of the handle (void* = hipStream_t) for event timing by the caller */
 int pgf_stream(pgf_handle h, void **stream_out);
 /* device time (ms) spent in the factor's trailing-update launches since the last call,
@@ -198,6 +203,8 @@ int pgf_batch_residual_norms(pgf_batch b, double *norms_out, double *norms_out_d
 /* all points / masks, instance-major: x[count][n], y[count][m], mask[count][n] */
 int pgf_batch_get_points(pgf_batch b, double *x, double *y);
 int pgf_batch_get_masks(pgf_batch b, uint8_t *mask);
+/* pgf_qp_measures for every instance: out[count][4] */
+int pgf_batch_measures(pgf_batch b, double active_tol, double *out);
 int pgf_batch_stream(pgf_batch b, void **stream_out);
 /* as pgf_profile_enable / pgf_profile_read, for the batch's trailing-update launches */
 int pgf_batch_profile_enable(pgf_batch b, int on);

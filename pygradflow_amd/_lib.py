@@ -63,6 +63,7 @@ SIGNATURES = {
     "pgf_qp_step_async": (C.c_int, [_h, C.c_uint, C.c_double]),
     "pgf_qp_sync": (C.c_int, [_h, _ip, _dp]),
     "pgf_qp_residual_norm": (C.c_int, [_h, _dp, C.c_void_p]),
+    "pgf_qp_measures": (C.c_int, [_h, C.c_double, _dp]),
     "pgf_stream": (C.c_int, [_h, C.POINTER(C.c_void_p)]),
     "pgf_profile_enable": (C.c_int, [_h, C.c_int]),
     "pgf_profile_read": (C.c_int, [_h, _dp, C.POINTER(C.c_int64), _dp, _dp]),
@@ -76,6 +77,7 @@ SIGNATURES = {
     "pgf_batch_residual_norms": (C.c_int, [_h, _dp, C.c_void_p]),
     "pgf_batch_get_points": (C.c_int, [_h, _dp, _dp]),
     "pgf_batch_get_masks": (C.c_int, [_h, _u8p]),
+    "pgf_batch_measures": (C.c_int, [_h, C.c_double, _dp]),
     "pgf_batch_stream": (C.c_int, [_h, C.POINTER(C.c_void_p)]),
     "pgf_batch_profile_enable": (C.c_int, [_h, C.c_int]),
     "pgf_batch_profile_read": (C.c_int, [_h, _dp, C.POINTER(C.c_int64), _dp]),

@@ -179,6 +179,18 @@ class BatchedDeviceNewton:
                         batch=self._b)
         return mk
 
+    def measures(self, active_tol=1e-8):
+        """[count][4] array: stat_res, cons_violation, bound_violation, ||y||_inf per local
+        instance (``Iterate.stat_res`` etc., evaluated on device)."""
+        if self._b is None:
+            rows = [s.measures(active_tol) for s in self.solvers]
+            return np.array([[r["stat_res"], r["cons_violation"], r["bound_violation"], r["y_inf"]]
+                             for r in rows]).reshape(self.count, 4)
+        out = np.empty((self.count, 4))
+        self._lib.check(self._lib.load().pgf_batch_measures(self._b, float(active_tol),
+                                                            self._lib.dptr(out)), batch=self._b)
+        return out
+
     def profile(self, on=True):
         if self._b is not None:
             self._lib.check(self._lib.load().pgf_batch_profile_enable(self._b, int(on)),

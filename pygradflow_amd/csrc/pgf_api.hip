@@ -34,6 +34,8 @@ struct pgf_solver {
   double *rhs = nullptr, *sol = nullptr, *dx = nullptr, *dy = nullptr;
   double *q = nullptr, *b = nullptr, *w = nullptr, *tmpn = nullptr, *partial = nullptr;
   double *red = nullptr, *scal = nullptr;  // scal[0] diff, scal[1] residual norm
+  double *meas = nullptr;                  // termination measures: partial maxima + 4 results
+  double *h_meas = nullptr;
   uint8_t *mask = nullptr, *mask_new = nullptr;
   int *idxI = nullptr, *idxA = nullptr, *pos = nullptr, *counts = nullptr;
   // pinned host mirrors
@@ -134,11 +136,12 @@ int pgf_create(int n, int m, int device, unsigned flags, pgf_handle *out) {
   A_(x, n) A_(y, m) A_(xn, n) A_(yn, m) A_(g, n) A_(c, m) A_(F, N) A_(b0full, n);
   A_(rhs, N + 1) A_(sol, N + 1) A_(dx, n) A_(dy, m);
   A_(q, n) A_(b, m) A_(w, m) A_(tmpn, n) A_(partial, (size_t)PGF_GEMVT_PARTS * (n ? n : 1));
-  A_(red, (N + 255) / 256 + 1) A_(scal, 4);
+  A_(red, (N + 255) / 256 + 1) A_(scal, 4) A_(meas, 4 * ((N + 255) / 256) + 4);
   A_(mask, n) A_(mask_new, n) A_(idxI, n) A_(idxA, n) A_(pos, n) A_(counts, 4);
 #undef A_
   if ((e = hipHostMalloc((void **)&h->h_counts, 4 * sizeof(int))) != hipSuccess ||
-      (e = hipHostMalloc((void **)&h->h_scal, 4 * sizeof(double))) != hipSuccess) {
+      (e = hipHostMalloc((void **)&h->h_scal, 4 * sizeof(double))) != hipSuccess ||
+      (e = hipHostMalloc((void **)&h->h_meas, 4 * sizeof(double))) != hipSuccess) {
     pgf_destroy(h);
     return PGF_HIP_ERROR + (int)e;
   }
@@ -168,11 +171,12 @@ int pgf_destroy(pgf_handle h) {
                   h->x,    h->y,    h->xn,  h->yn,   h->g,    h->c,        h->F,    h->b0full,
                   h->rhs,  h->sol,  h->dx,  h->dy,   h->q,    h->b,        h->w,    h->tmpn,
                   h->partial, h->red, h->scal, h->mask, h->mask_new, h->idxI, h->idxA, h->pos,
-                  h->counts};
+                  h->counts, h->meas};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h->h_counts) (void)hipHostFree(h->h_counts);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
+  if (h->h_meas) (void)hipHostFree(h->h_meas);
   {
     SparseDev &sp = h->sp;
     void *sps[] = {sp.pos, sp.Hptr, sp.Hrow, sp.Hcol, sp.Hslot, sp.Jptr, sp.Jcol, sp.Jslot, sp.JTptr,
@@ -875,6 +879,7 @@ struct pgf_batch_s {
   BInst *tab = nullptr;
   int *ctl = nullptr, *flags_out = nullptr, *h_flags = nullptr;
   double *diff_out = nullptr, *norm_out = nullptr, *h_diff = nullptr, *h_norm = nullptr;
+  double *red4 = nullptr, *meas_out = nullptr, *h_meas = nullptr;
   BatchScalars sc{};
   bool outer_set = false, eval_fresh = false, step_pending = false, have_mask = false;
   bool all_factored = false;
@@ -931,6 +936,11 @@ int pgf_batch_create(const pgf_handle *handles, int count, pgf_batch *out) {
       (e = hipMalloc((void **)&b->flags_out, (size_t)count * 3 * sizeof(int))) != hipSuccess ||
       (e = hipMalloc((void **)&b->diff_out, count * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void **)&b->norm_out, count * sizeof(double))) != hipSuccess ||
+      (e = hipMalloc((void **)&b->red4,
+                     (size_t)count * 4 * ((h0->n + h0->m + 255) / 256 + 1) * sizeof(double))) !=
+          hipSuccess ||
+      (e = hipMalloc((void **)&b->meas_out, (size_t)count * 4 * sizeof(double))) != hipSuccess ||
+      (e = hipHostMalloc((void **)&b->h_meas, (size_t)count * 4 * sizeof(double))) != hipSuccess ||
       (e = hipHostMalloc((void **)&b->h_flags, (size_t)count * 3 * sizeof(int))) != hipSuccess ||
       (e = hipHostMalloc((void **)&b->h_diff, count * sizeof(double))) != hipSuccess ||
       (e = hipHostMalloc((void **)&b->h_norm, count * sizeof(double))) != hipSuccess) {
@@ -1007,9 +1017,9 @@ int pgf_batch_destroy(pgf_batch b) {
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   for (void *p : {(void *)b->tab, (void *)b->ctl, (void *)b->flags_out, (void *)b->diff_out,
-                  (void *)b->norm_out})
+                  (void *)b->norm_out, (void *)b->red4, (void *)b->meas_out})
     if (p) (void)hipFree(p);
-  for (void *p : {(void *)b->h_flags, (void *)b->h_diff, (void *)b->h_norm})
+  for (void *p : {(void *)b->h_flags, (void *)b->h_diff, (void *)b->h_norm, (void *)b->h_meas})
     if (p) (void)hipHostFree(p);
   for (hipEvent_t e : b->prof.pool) (void)hipEventDestroy(e);
   for (auto &sp : b->prof.update_spans) {
@@ -1191,6 +1201,22 @@ int pgf_batch_residual_norms(pgf_batch b, double *norms_out, double *norms_out_d
   return PGF_OK;
 }
 
+int pgf_batch_measures(pgf_batch b, double active_tol, double *out) {
+  if (!b || !out) return PGF_INVALID;
+  if (b->step_pending) return bfail(b, PGF_NOT_READY, "pgf_batch_sync the previous step first");
+  (void)hipSetDevice(b->device);
+  if (!b->outer_set) return bfail(b, PGF_NOT_READY, "pgf_batch_advance_outer first");
+  batch_eval(b);
+  batch_launch_measures(b->stream, b->tab, b->B, b->sc, PGF_GEMVT_PARTS, active_tol, b->red4,
+                        b->meas_out);
+  b->eval_fresh = false;  // tmpn / w were reused
+  BHIPCHK(b, hipMemcpyAsync(b->h_meas, b->meas_out, (size_t)b->B * 4 * sizeof(double),
+                            hipMemcpyDeviceToHost, b->stream));
+  BHIPCHK(b, hipStreamSynchronize(b->stream));
+  std::memcpy(out, b->h_meas, (size_t)b->B * 4 * sizeof(double));
+  return PGF_OK;
+}
+
 int pgf_batch_get_points(pgf_batch b, double *x, double *y) {
   if (!b) return PGF_INVALID;
   if (b->step_pending) return bfail(b, PGF_NOT_READY, "pgf_batch_sync the previous step first");
@@ -1217,6 +1243,35 @@ int pgf_batch_get_masks(pgf_batch b, uint8_t *mask) {
       BHIPCHK(b, hipMemcpyAsync(mask + (size_t)i * b->n, b->hs[i]->mask, b->n,
                                 hipMemcpyDeviceToHost, b->stream));
   BHIPCHK(b, hipStreamSynchronize(b->stream));
+  return PGF_OK;
+}
+
+int pgf_qp_measures(pgf_handle h, double active_tol, double *out) {
+  if (!h || !out) return PGF_INVALID;
+  if (!h->qp_mode || !h->point_set || !h->bounds_set)
+    return fail(h, PGF_NOT_READY, "pgf_set_bounds, pgf_qp_set_problem, pgf_qp_set_point first");
+  (void)hipSetDevice(h->device);
+  hipStream_t s = h->stream;
+  const int n = h->n, m = h->m;
+  // c = A x - b and r = Q x + q + A'y (no rho term: iterate.py:141, 176)
+  launch_copy(s, h->w, h->y, m);
+  if (h->sparse) {
+    const SparseDev &sp = h->sp;
+    sp_launch_spmv(s, m, sp.Jptr, sp.Jcol, sp.Jval, h->x, h->b, -1.0, h->c);
+    sp_launch_spmvT(s, n, sp.JTptr, sp.JTrow, sp.JTmap, sp.Jval, h->w, h->q, h->tmpn);
+    sp_launch_spmv(s, n, sp.Hptr, sp.Hcol, sp.Hval, h->x, h->tmpn, 1.0, h->F);
+  } else {
+    launch_gemv_rows(s, m, n, h->J, h->ldj, h->x, h->b, -1.0, h->c);
+    launch_gemvT(s, m, n, h->J, h->ldj, h->w, h->q, h->partial, PGF_GEMVT_PARTS, h->tmpn);
+    launch_gemv_rows(s, n, n, h->H, h->ldh, h->x, h->tmpn, 1.0, h->F);
+  }
+  const int nb = (n + m + 255) / 256;
+  double *res = h->meas + 4 * nb;
+  launch_measures(s, n, m, active_tol, h->x, h->y, h->F, h->c, h->lb, h->ub, h->meas, res);
+  int rc;
+  if ((rc = down(h, h->h_meas, res, 4 * sizeof(double)))) return rc;
+  HIPCHK(h, hipStreamSynchronize(s));
+  std::memcpy(out, h->h_meas, 4 * sizeof(double));
   return PGF_OK;
 }
 

@@ -97,6 +97,8 @@ void batch_launch_step_update(hipStream_t s, const BInst *tab, int B, const Batc
                               double *diff_out, int *flags_out);
 void batch_launch_res_norm(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc,
                            double *norm_out);
+void batch_launch_measures(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc,
+                           int nparts, double active_tol, double *red4, double *out);
 // pgf_ldlt.hip
 void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m, int OB,
                              PgfProfile *prof);

@@ -41,3 +41,6 @@ void launch_unscaled_res_norm(hipStream_t s, int n, int m, double dt, const doub
                               const double *g, const double *c, const double *lb,
                               const double *ub, double *red, double *out);
 void launch_final_reduce(hipStream_t s, const double *red, int cnt, double *out, int take_sqrt);
+void launch_measures(hipStream_t s, int n, int m, double active_tol, const double *x,
+                     const double *y, const double *r, const double *c, const double *lb,
+                     const double *ub, double *red, double *out);

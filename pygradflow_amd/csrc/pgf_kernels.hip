@@ -364,6 +364,95 @@ __device__ __forceinline__ void b_unscaled_res_sq(
   if (threadIdx.x == 0) red[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
+// ---------------------------------------------------------------- termination measures
+// Iterate-level residuals the outer loop tests between Newton calls (SURVEY.md 8f rank 4;
+// reference iterate.py:136-181, active_set.py:4-29), per-block maxima of
+//   [0] | r + d |   r = obj_grad + J'y (given), d = bounds_dual        -> stat_res
+//   [1] | c |                                                         -> cons_violation
+//   [2] max(lb - x, 0), max(x - ub, 0)                                -> bound_violation
+//   [3] | y |                                                         -> DualNormUpdate
+// written to red[4 * blockIdx.x + k].  np.maximum / np.linalg.norm(inf) propagate NaN;
+// fmax does not, so a NaN entry is forwarded explicitly.
+__device__ __forceinline__ double nan_max(double a, double b) {
+  return (a != a || b != b) ? (a + b) : fmax(a, b);
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = nan_max(v, __shfl_down(v, off));
+  return v;
+}
+
+__device__ __forceinline__ void b_measures(int n, int m, double active_tol,
+                                           const double *__restrict__ x,
+                                           const double *__restrict__ y,
+                                           const double *__restrict__ r,
+                                           const double *__restrict__ c,
+                                           const double *__restrict__ lb,
+                                           const double *__restrict__ ub,
+                                           double *__restrict__ red) {
+  __shared__ double part[4][4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+  if (i < n) {
+    const double xi = x[i], lo = lb[i], hi = ub[i], ri = r[i];
+    const bool al = fabs(xi - lo) <= active_tol;
+    const bool au = fabs(hi - xi) <= active_tol;
+    const double nr = -ri;
+    double d = 0.0;
+    if (al && au)
+      d = nr;
+    else if (au)
+      d = (nr != nr) ? nr : fmax(nr, 0.0);
+    else if (al)
+      d = (nr != nr) ? nr : fmin(nr, 0.0);
+    v0 = fabs(ri + d);
+    const double bl = lo - xi, bu = xi - hi;
+    v2 = nan_max((bl != bl) ? bl : fmax(bl, 0.0), (bu != bu) ? bu : fmax(bu, 0.0));
+  } else if (i < n + m) {
+    v1 = fabs(c[i - n]);
+    v3 = fabs(y[i - n]);
+  }
+  v0 = wave_max(v0);
+  v1 = wave_max(v1);
+  v2 = wave_max(v2);
+  v3 = wave_max(v3);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    part[w][0] = v0;
+    part[w][1] = v1;
+    part[w][2] = v2;
+    part[w][3] = v3;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int k = threadIdx.x;
+    red[4 * blockIdx.x + k] =
+        nan_max(nan_max(part[0][k], part[1][k]), nan_max(part[2][k], part[3][k]));
+  }
+}
+
+// out[k] = max over blocks of red[4 b + k]
+__device__ __forceinline__ void b_measures_final(const double *__restrict__ red, int nb,
+                                                 double *__restrict__ out) {
+  __shared__ double part[4][4];
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < nb; b += 256)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = nan_max(v[k], red[4 * b + k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = wave_max(v[k]);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) part[w][k] = v[k];
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int k = threadIdx.x;
+    out[k] = nan_max(nan_max(part[0][k], part[1][k]), nan_max(part[2][k], part[3][k]));
+  }
+}
+
 // ---------------------------------------------------------------- single-instance kernels
 __global__ void k_scale_bounds(int n, double lamb, const double *__restrict__ lb,
     const double *__restrict__ ub, double *__restrict__ slb, double *__restrict__ sub) {
@@ -577,6 +666,32 @@ void launch_final_reduce(hipStream_t s, const double *red, int cnt, double *out,
   hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(256), 0, s, red, cnt, out, take_sqrt);
 }
 
+__global__ __launch_bounds__(256) void k_measures(int n, int m, double active_tol,
+                                                  const double *__restrict__ x,
+                                                  const double *__restrict__ y,
+                                                  const double *__restrict__ r,
+                                                  const double *__restrict__ c,
+                                                  const double *__restrict__ lb,
+                                                  const double *__restrict__ ub,
+                                                  double *__restrict__ red) {
+  b_measures(n, m, active_tol, x, y, r, c, lb, ub, red);
+}
+
+__global__ __launch_bounds__(256) void k_measures_final(const double *__restrict__ red, int nb,
+                                                        double *__restrict__ out) {
+  b_measures_final(red, nb, out);
+}
+
+void launch_measures(hipStream_t s, int n, int m, double active_tol, const double *x,
+                     const double *y, const double *r, const double *c, const double *lb,
+                     const double *ub, double *red, double *out) {
+  const int nb = (n + m + 255) / 256;
+  if (nb)
+    hipLaunchKernelGGL(k_measures, dim3(nb), dim3(256), 0, s, n, m, active_tol, x, y, r, c, lb, ub,
+                       red);
+  hipLaunchKernelGGL(k_measures_final, dim3(1), dim3(256), 0, s, red, nb, out);
+}
+
 // ================================================================ batched kernels
 // Same bodies as above, one instance per blockIdx.z, sizes read on the device (BInst in
 // pgf_internal.h).  Nothing here needs a host round trip.
@@ -781,4 +896,53 @@ void batch_launch_res_norm(hipStream_t s, const BInst *tab, int B, const BatchSc
   if (nb)
     hipLaunchKernelGGL(kb_unscaled_res_sq, dim3(nb, 1, B), dim3(256), 0, s, tab, sc.n, sc.m, sc.dt);
   hipLaunchKernelGGL(kb_norm_final, dim3(1, 1, B), dim3(256), 0, s, tab, nb, norm_out);
+}
+
+// r = Q x + (q + A'y) into tmpn / g is NOT touched: the measures use their own vector (F is
+// free between steps).  which 2: F[0:n] = H x + tmpn (after kb_sum_partials with w = y)
+__global__ void kb_copy_y_to_w(const BInst *__restrict__ tab, int m) {
+  const BInst &I = tab[blockIdx.z];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) I.w[i] = I.y[i];
+}
+
+__global__ __launch_bounds__(256) void kb_gemv_stat(const BInst *__restrict__ tab, int n) {
+  const BInst &I = tab[blockIdx.z];
+  b_gemv_rows(n, n, I.H, I.ldh, I.x, I.tmpn, 1.0, I.F);
+}
+
+__global__ __launch_bounds__(256) void kb_measures(const BInst *__restrict__ tab, int n, int m,
+                                                   double active_tol, double *__restrict__ red4,
+                                                   int nb) {
+  const BInst &I = tab[blockIdx.z];
+  b_measures(n, m, active_tol, I.x, I.y, I.F, I.c, I.lb, I.ub, red4 + (size_t)blockIdx.z * 4 * nb);
+}
+
+__global__ __launch_bounds__(256) void kb_measures_final(const double *__restrict__ red4, int nb,
+                                                         double *__restrict__ out) {
+  b_measures_final(red4 + (size_t)blockIdx.z * 4 * nb, nb, out + 4 * blockIdx.z);
+}
+
+// c must be fresh (batch_launch_eval).  Leaves tmpn / w overwritten: the caller marks the
+// evaluation stale.
+void batch_launch_measures(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc,
+                           int nparts, double active_tol, double *red4, double *out) {
+  const int n = sc.n, m = sc.m;
+  const int nb = (n + m + 255) / 256;
+  if (n) {
+    int used = 0;
+    if (m) {
+      hipLaunchKernelGGL(kb_copy_y_to_w, gb(m, 256, B), dim3(256), 0, s, tab, m);
+      const int chunk = (m + nparts - 1) / nparts;
+      used = (m + chunk - 1) / chunk;
+      hipLaunchKernelGGL(kb_gemvT_partial, dim3((n + 255) / 256, used, B), dim3(256), 0, s, tab, n,
+                         m, chunk);
+    }
+    hipLaunchKernelGGL(kb_sum_partials, gb(n, 256, B), dim3(256), 0, s, tab, n, used);
+    hipLaunchKernelGGL(kb_gemv_stat, gb(n, 4, B), dim3(256), 0, s, tab, n);
+  }
+  if (nb)
+    hipLaunchKernelGGL(kb_measures, dim3(nb, 1, B), dim3(256), 0, s, tab, n, m, active_tol, red4,
+                       nb);
+  hipLaunchKernelGGL(kb_measures_final, dim3(1, 1, B), dim3(256), 0, s, red4, nb, out);
 }

@@ -103,9 +103,71 @@ class Iterate:
     def dist(self, other):
         return float(np.sqrt(np.sum((self.x - other.x) ** 2) + np.sum((self.y - other.y) ** 2)))
 
+    # termination measures, reference iterate.py:136-181 -------------------
+    @functools.cached_property
+    def active_set(self):
+        return ActiveSet(self)
+
+    @functools.cached_property
+    def bounds_dual(self):
+        """Multiplier estimate of the bounds: the part of -(grad f + J'y) that a bound can
+        carry (non-negative at an upper bound, non-positive at a lower one, all of it where
+        both coincide)."""
+        r = -(self.obj_grad + self.cons_jac.T.dot(self.y))
+        act = self.active_set
+        d = np.zeros_like(self.x)
+        d[act.at_upper] = np.maximum(r[act.at_upper], 0.0)
+        d[act.at_lower] = np.minimum(r[act.at_lower], 0.0)
+        d[act.at_both] = r[act.at_both]
+        return d
+
+    @functools.cached_property
+    def bound_violation(self):
+        lb, ub = self.problem.var_lb, self.problem.var_ub
+        below = float(np.linalg.norm(np.maximum(lb - self.x, 0.0), np.inf))
+        above = float(np.linalg.norm(np.maximum(self.x - ub, 0.0), np.inf))
+        return max(below, above)
+
+    @functools.cached_property
+    def cons_violation(self):
+        c = self.cons
+        return float(np.linalg.norm(c, np.inf)) if c.size else 0.0
+
+    @functools.cached_property
+    def stat_res(self):
+        r = self.obj_grad + self.cons_jac.T.dot(self.y) + self.bounds_dual
+        return float(np.linalg.norm(r, np.inf))
+
+    def is_feasible(self, tol):
+        return self.cons_violation <= tol and self.bound_violation <= tol
+
+    @property
+    def total_res(self):
+        return max(self.cons_violation, self.bound_violation, self.stat_res)
+
     def check_eval(self):
         self.obj
         self.obj_grad
         if self.problem.num_cons > 0:
             self.cons
             self.cons_jac
+
+
+class ActiveSet:
+    """Which variables sit at (or beyond) a bound, to ``params.active_tol``
+    (reference active_set.py:4-29).  ``at_lower`` / ``at_upper`` exclude ``at_both``."""
+
+    def __init__(self, iterate):
+        tol = getattr(iterate.params, "active_tol", 1e-8)
+        lb, ub, x = iterate.problem.var_lb, iterate.problem.var_ub, iterate.x
+        near_lb = np.absolute(x - lb) <= tol
+        near_ub = np.absolute(ub - x) <= tol
+        self.violated = np.logical_or(lb - x > tol, x - ub > tol)
+        self.at_either = np.logical_or(near_lb, near_ub)
+        self.at_both = np.logical_and(near_lb, near_ub)
+        self.at_lower = np.logical_and(near_lb, np.logical_not(self.at_both))
+        self.at_upper = np.logical_and(near_ub, np.logical_not(self.at_both))
+
+    @property
+    def satisfied(self):
+        return np.logical_not(self.violated)

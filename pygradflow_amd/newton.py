@@ -305,6 +305,14 @@ class DeviceNewton:
                    self._hd.h, "pgf_qp_residual_norm")
         return out.value
 
+    def measures(self, active_tol=1e-8):
+        """Termination measures of the device point: dict(stat_res, cons_violation,
+        bound_violation, y_inf) -- ``Iterate.stat_res`` etc. without moving the point."""
+        out = np.empty(4)
+        _lib.check(self._lib.pgf_qp_measures(self._hd.h, float(active_tol), _lib.dptr(out)),
+                   self._hd.h, "pgf_qp_measures")
+        return dict(stat_res=out[0], cons_violation=out[1], bound_violation=out[2], y_inf=out[3])
+
     def profile(self, on=True):
         _lib.check(self._lib.pgf_profile_enable(self._hd.h, int(on)), self._hd.h)
 

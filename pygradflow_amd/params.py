@@ -70,6 +70,7 @@ class Params:
     active_set_tau: Optional[float] = None
     report_rcond: bool = False
     inertia_correction: bool = False
+    active_tol: float = 1e-8
     # step-size control (reference params.py:206-217)
     theta_max: float = 0.9
     theta_ref: float = 0.5

@@ -15,7 +15,7 @@ def case_names():
         os.path.basename(p)[:-4]
         for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
         if not p.endswith("linear_solver_5x5.npz")
-        and not os.path.basename(p).startswith(("extras_", "ctl_"))
+        and not os.path.basename(p).startswith(("extras_", "ctl_", "measures_"))
     )
 
 

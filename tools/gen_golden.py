@@ -239,10 +239,59 @@ def controller_cases():
                             quartic_store(qn))
 
 
+def measures_cases():
+    """Termination measures of the reference Iterate (iterate.py:136-181) and the default
+    penalty update (penalty.py:46-74) at points with variables exactly on, near and beyond
+    their bounds."""
+    from pygradflow.penalty import DualNormUpdate
+
+    rng = np.random.default_rng(5)
+    out = {}
+    probs = dict(
+        lq=P.dense_qp(96, 24, seed=1, boxed_frac=0.25),
+        quartic=P.quartic_nlp(12, 4, seed=3),
+        box=P.box_qp(256, seed=0),
+    )
+    stores = dict(lq=qp_store(probs["lq"]), quartic=quartic_store(probs["quartic"]),
+                  box=qp_store(probs["box"]))
+    for key, prob in probs.items():
+        n, m = prob.num_vars, prob.num_cons
+        params = Params()
+        pts = []
+        for k in range(4):
+            x = 0.3 * rng.standard_normal(n)
+            fin_lb, fin_ub = np.isfinite(prob.var_lb), np.isfinite(prob.var_ub)
+            pick = rng.random(n)
+            x = np.where(fin_lb & (pick < 0.25), prob.var_lb, x)                  # on the bound
+            x = np.where(fin_ub & (pick > 0.75), prob.var_ub + 5e-9, x)          # within tol
+            x = np.where(fin_ub & (pick > 0.95), prob.var_ub + 0.1, x)           # violated
+            y = (10.0 ** k) * rng.standard_normal(m)
+            it = Iterate(prob, params, x, y)
+            act = it.active_set
+            pts.append(dict(x=x, y=y, stat_res=it.stat_res, cons_violation=it.cons_violation,
+                            bound_violation=it.bound_violation, bounds_dual=it.bounds_dual,
+                            at_lower=act.at_lower, at_upper=act.at_upper, at_both=act.at_both,
+                            violated=act.violated))
+        # DualNormUpdate along the growing multipliers
+        pen = DualNormUpdate(prob, params)
+        rho = [pen.initial(None)]
+        for pt in pts:
+            rho.append(pen.update(None, Iterate(prob, params, pt["x"], pt["y"])).next_rho)
+        rec = {f"{name}": np.array([pt[name] for pt in pts]) for name in pts[0]}
+        rec["rho_trace"] = np.array(rho)
+        rec.update(n=n, m=m, var_lb=prob.var_lb, var_ub=prob.var_ub)
+        rec.update({"problem/" + k: v for k, v in stores[key].items()})
+        np.savez_compressed(os.path.join(OUT, f"measures_{key}.npz"), **rec)
+        print(f"measures_{key}: stat_res {rec['stat_res']}, rho {rec['rho_trace']}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--only-controllers" in sys.argv:
         controller_cases()
+        return
+    if "--only-measures" in sys.argv:
+        measures_cases()
         return
     # the reference's own fixture problems, loaded by path (this repository has a `tests`
     # package of its own, which would shadow the reference's)
@@ -313,6 +362,7 @@ def main():
                qp_store(d2b))
 
     controller_cases()
+    measures_cases()
     linear_solver_cases()
 
 
