@@ -430,13 +430,15 @@ __device__ __forceinline__ int gj_inverse8(double *M, int lane, int *bad) {
   return neg;
 }
 
-// invert the blocks eliminated at this level: i = s, 3s, 5s, ... (i mod 2s == s)
-__global__ __launch_bounds__(64) void k_bcr_invert(const double *__restrict__ D,
-                                                   double *__restrict__ Dinv, int nb, int s,
-                                                   int first, int stride, int *__restrict__ flags) {
-  __shared__ double M[64];
-  const int i = first + blockIdx.x * stride, lane = threadIdx.x;
-  if (i >= nb) return;
+// ---- per-block work of one wavefront (lane = threadIdx.x & 63); `sm` is the wavefront's own
+// LDS scratch of BCR_SCRATCH doubles.  Used by the one-block-per-workgroup kernels of the
+// large levels and by the fused tail kernel below.
+#define BCR_SCRATCH (3 * 64 + 8)
+
+__device__ __forceinline__ void bcr_invert_block(const double *__restrict__ D,
+                                                 double *__restrict__ Dinv, int i, int lane,
+                                                 double *sm, int *__restrict__ flags) {
+  double *M = sm;
   M[lane] = D[(int64_t)i * 64 + lane];
   int bad = 0;
   const int neg = gj_inverse8(M, lane, &bad);
@@ -445,7 +447,6 @@ __global__ __launch_bounds__(64) void k_bcr_invert(const double *__restrict__ D,
     if (bad) atomicOr(&flags[0], 1);
     if (neg) atomicAdd(&flags[1], neg);
   }
-  (void)s;
 }
 
 // 8 x 8 product helper: out[r][c] = sum_k A[r][k] B[k][c], operands in LDS
@@ -456,13 +457,12 @@ __device__ __forceinline__ double mm8(const double *A, const double *B, int r, i
   return acc;
 }
 
-// reduce the kept blocks of this level: i = 0, 2s, 4s, ...
-__global__ __launch_bounds__(64) void k_bcr_reduce(double *__restrict__ D, double *__restrict__ L,
-                                                   double *__restrict__ U, double *__restrict__ F,
-                                                   const double *__restrict__ Dinv, int nb, int s) {
-  __shared__ double A[64], B[64], T[64], fs[8];
-  const int i = blockIdx.x * 2 * s, lane = threadIdx.x;
-  if (i >= nb) return;
+// kept block i of the level with stride s (neighbours i - s, i + s are eliminated)
+__device__ __forceinline__ void bcr_reduce_block(double *__restrict__ D, double *__restrict__ L,
+                                                 double *__restrict__ U, double *__restrict__ F,
+                                                 const double *__restrict__ Dinv, int nb, int s,
+                                                 int i, int lane, double *sm) {
+  double *A = sm, *B = sm + 64, *T = sm + 128, *fs = sm + 192;
   const int r = lane >> 3, c = lane & 7;
   double dv = D[(int64_t)i * 64 + lane];
   double fv = (lane < 8) ? F[(int64_t)i * 8 + lane] : 0.0;
@@ -508,18 +508,14 @@ __global__ __launch_bounds__(64) void k_bcr_reduce(double *__restrict__ D, doubl
   if (lane < 8) F[(int64_t)i * 8 + lane] = fv;
 }
 
-// back-substitution of the blocks eliminated at this level (i mod 2s == s), and of the
-// single remaining block when s == 0 (first = 0, stride irrelevant):
-//   x_i = inv(D_i) (f_i - L_i x_{i-s} - U_i x_{i+s})
-__global__ __launch_bounds__(64) void k_bcr_back(const double *__restrict__ Dinv,
-                                                 const double *__restrict__ L,
-                                                 const double *__restrict__ U,
-                                                 const double *__restrict__ F,
-                                                 double *__restrict__ X, int nb, int s, int first,
-                                                 int stride) {
-  __shared__ double t[8], xl[8], xr[8];
-  const int i = first + blockIdx.x * stride, lane = threadIdx.x;
-  if (i >= nb) return;
+// x_i = inv(D_i) (f_i - L_i x_{i-s} - U_i x_{i+s});  s == 0: the last remaining block
+__device__ __forceinline__ void bcr_back_block(const double *__restrict__ Dinv,
+                                               const double *__restrict__ L,
+                                               const double *__restrict__ U,
+                                               const double *__restrict__ F,
+                                               double *__restrict__ X, int nb, int s, int i,
+                                               int lane, double *sm) {
+  double *t = sm, *xl = sm + 8, *xr = sm + 16;
   const int le = i - s, ri = i + s;
   const bool hl = (s > 0) && le >= 0, hr = (s > 0) && ri < nb;
   if (lane < 8) {
@@ -544,6 +540,77 @@ __global__ __launch_bounds__(64) void k_bcr_back(const double *__restrict__ Dinv
   }
 }
 
+// invert the blocks eliminated at this level: i = s, 3s, 5s, ... (i mod 2s == s)
+__global__ __launch_bounds__(64) void k_bcr_invert(const double *__restrict__ D,
+                                                   double *__restrict__ Dinv, int nb, int s,
+                                                   int first, int stride, int *__restrict__ flags) {
+  __shared__ double sm[BCR_SCRATCH];
+  const int i = first + blockIdx.x * stride;
+  if (i >= nb) return;
+  bcr_invert_block(D, Dinv, i, threadIdx.x, sm, flags);
+  (void)s;
+}
+
+// reduce the kept blocks of this level: i = 0, 2s, 4s, ...
+__global__ __launch_bounds__(64) void k_bcr_reduce(double *__restrict__ D, double *__restrict__ L,
+                                                   double *__restrict__ U, double *__restrict__ F,
+                                                   const double *__restrict__ Dinv, int nb, int s) {
+  __shared__ double sm[BCR_SCRATCH];
+  const int i = blockIdx.x * 2 * s;
+  if (i >= nb) return;
+  bcr_reduce_block(D, L, U, F, Dinv, nb, s, i, threadIdx.x, sm);
+}
+
+// back-substitution of the blocks eliminated at this level (i mod 2s == s)
+__global__ __launch_bounds__(64) void k_bcr_back(const double *__restrict__ Dinv,
+                                                 const double *__restrict__ L,
+                                                 const double *__restrict__ U,
+                                                 const double *__restrict__ F,
+                                                 double *__restrict__ X, int nb, int s, int first,
+                                                 int stride) {
+  __shared__ double sm[BCR_SCRATCH];
+  const int i = first + blockIdx.x * stride;
+  if (i >= nb) return;
+  bcr_back_block(Dinv, L, U, F, X, nb, s, i, threadIdx.x, sm);
+}
+
+// All levels from stride s0 upwards, the last block, and the matching back-substitution
+// levels in ONE workgroup of 16 wavefronts: at these levels at most BCR_TAIL_BLOCKS blocks
+// are left and every level was two dependent launches of a few microseconds each
+// (launch-bound).  Wavefronts take blocks round-robin; a workgroup barrier separates the
+// invert / reduce / back phases (all wavefronts of a workgroup share the CU's L1, so the
+// barrier's workgroup-scope fence orders the global-memory hand-over).
+#define BCR_TAIL_BLOCKS 512
+__global__ __launch_bounds__(1024) void k_bcr_tail(double *__restrict__ D, double *__restrict__ L,
+                                                   double *__restrict__ U, double *__restrict__ F,
+                                                   double *__restrict__ Dinv, double *__restrict__ X,
+                                                   int nb, int s0, int *__restrict__ flags) {
+  __shared__ double smem[16 * BCR_SCRATCH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double *sm = smem + wave * BCR_SCRATCH;
+  int top = 0;
+  for (int st = s0; st < nb; st *= 2) {
+    const int ne = (nb - st + 2 * st - 1) / (2 * st);
+    for (int e = wave; e < ne; e += 16) bcr_invert_block(D, Dinv, st + e * 2 * st, lane, sm, flags);
+    __syncthreads();
+    const int nk = (nb + 2 * st - 1) / (2 * st);
+    for (int k = wave; k < nk; k += 16) bcr_reduce_block(D, L, U, F, Dinv, nb, st, k * 2 * st, lane, sm);
+    __syncthreads();
+    top = st;
+  }
+  if (wave == 0) {
+    bcr_invert_block(D, Dinv, 0, lane, sm, flags);
+    bcr_back_block(Dinv, L, U, F, X, nb, 0, 0, lane, sm);
+  }
+  __syncthreads();
+  for (int st = top; st >= s0 && st >= 1; st /= 2) {
+    const int ne = (nb - st + 2 * st - 1) / (2 * st);
+    for (int e = wave; e < ne; e += 16)
+      bcr_back_block(Dinv, L, U, F, X, nb, st, st + e * 2 * st, lane, sm);
+    __syncthreads();
+  }
+}
+
 __global__ void k_bcr_scatter(const double *__restrict__ X, double *__restrict__ out, int N) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) out[i] = X[i];
@@ -557,8 +624,13 @@ void sp_launch_bcr_solve(hipStream_t s, const SparseDev &sp, int N, int *flags) 
   const int nb = (N + 7) / 8;
   hipLaunchKernelGGL(k_bcr_extract, dim3(nb), dim3(64), 0, s, sp.band, sp.ldb, sp.bw, sp.brhs, N, nb,
                      sp.bD, sp.bL, sp.bU, sp.bF);
-  int top = 1;
-  for (int st = 1; st < nb; st *= 2) {
+  // levels with many blocks: one workgroup per block; from the first level with at most
+  // BCR_TAIL_BLOCKS blocks left: everything in one workgroup (PGF_BCR_TAIL=0 disables)
+  static const bool use_tail = !(getenv("PGF_BCR_TAIL") && atoi(getenv("PGF_BCR_TAIL")) == 0);
+  int st = 1;
+  for (; st < nb; st *= 2) {
+    const int left = (nb + st - 1) / st;  // blocks still in play before this level
+    if (use_tail && left <= BCR_TAIL_BLOCKS) break;
     const int ne = (nb - st + 2 * st - 1) / (2 * st);  // eliminated: st, 3st, ...
     if (ne > 0)
       hipLaunchKernelGGL(k_bcr_invert, dim3(ne), dim3(64), 0, s, sp.bD, sp.bDinv, nb, st, st,
@@ -566,18 +638,15 @@ void sp_launch_bcr_solve(hipStream_t s, const SparseDev &sp, int N, int *flags) 
     const int nk = (nb + 2 * st - 1) / (2 * st);       // kept: 0, 2st, ...
     hipLaunchKernelGGL(k_bcr_reduce, dim3(nk), dim3(64), 0, s, sp.bD, sp.bL, sp.bU, sp.bF, sp.bDinv,
                        nb, st);
-    top = st;
   }
-  // the last remaining block (index 0)
-  hipLaunchKernelGGL(k_bcr_invert, dim3(1), dim3(64), 0, s, sp.bD, sp.bDinv, nb, 0, 0, 1, flags);
-  hipLaunchKernelGGL(k_bcr_back, dim3(1), dim3(64), 0, s, sp.bDinv, sp.bL, sp.bU, sp.bF, sp.bX, nb, 0,
-                     0, 1);
-  if (nb > 1)
-    for (int st = top; st >= 1; st /= 2) {
-      const int ne = (nb - st + 2 * st - 1) / (2 * st);
-      if (ne > 0)
-        hipLaunchKernelGGL(k_bcr_back, dim3(ne), dim3(64), 0, s, sp.bDinv, sp.bL, sp.bU, sp.bF, sp.bX,
-                           nb, st, st, 2 * st);
-    }
+  // st: first level NOT done above (st >= nb: only the last block is left)
+  hipLaunchKernelGGL(k_bcr_tail, dim3(1), dim3(1024), 0, s, sp.bD, sp.bL, sp.bU, sp.bF, sp.bDinv,
+                     sp.bX, nb, st, flags);
+  for (int bs = st / 2; bs >= 1; bs /= 2) {
+    const int ne = (nb - bs + 2 * bs - 1) / (2 * bs);
+    if (ne > 0)
+      hipLaunchKernelGGL(k_bcr_back, dim3(ne), dim3(64), 0, s, sp.bDinv, sp.bL, sp.bU, sp.bF, sp.bX,
+                         nb, bs, bs, 2 * bs);
+  }
   hipLaunchKernelGGL(k_bcr_scatter, g1(N), dim3(256), 0, s, sp.bX, sp.brhs, N);
 }
