@@ -575,40 +575,59 @@ __global__ __launch_bounds__(64) void k_bcr_back(const double *__restrict__ Dinv
 }
 
 // All levels from stride s0 upwards, the last block, and the matching back-substitution
-// levels in ONE workgroup of 16 wavefronts: at these levels at most BCR_TAIL_BLOCKS blocks
-// are left and every level was two dependent launches of a few microseconds each
-// (launch-bound).  Wavefronts take blocks round-robin; a workgroup barrier separates the
-// invert / reduce / back phases (all wavefronts of a workgroup share the CU's L1, so the
-// barrier's workgroup-scope fence orders the global-memory hand-over).
-#define BCR_TAIL_BLOCKS 512
-__global__ __launch_bounds__(1024) void k_bcr_tail(double *__restrict__ D, double *__restrict__ L,
-                                                   double *__restrict__ U, double *__restrict__ F,
-                                                   double *__restrict__ Dinv, double *__restrict__ X,
-                                                   int nb, int s0, int *__restrict__ flags) {
+// levels in ONE workgroup: at most BCR_TAIL_BLOCKS blocks are still in play there, every level
+// was two dependent launches of a few microseconds each (launch-bound), and the whole
+// remaining system fits in LDS.  The in-play blocks (global index j * s0) are copied to LDS
+// in compact order, reduced with strides 1, 2, 4, ... of the compact index by 16 wavefronts
+// taking blocks round-robin (a workgroup barrier between the invert / reduce / back phases),
+// and only their solution X goes back to HBM for the lower back-substitution levels.
+// (A first version ran the tail on the global arrays with up to 512 blocks: every block
+// operation is a chain of dependent HBM round trips, one CU working through them was 3x
+// slower than the launches it replaced.)
+#define BCR_TAIL_BLOCKS 32
+__global__ __launch_bounds__(1024) void k_bcr_tail(const double *__restrict__ D,
+                                                   const double *__restrict__ L,
+                                                   const double *__restrict__ U,
+                                                   const double *__restrict__ F,
+                                                   double *__restrict__ X, int nb, int s0,
+                                                   int *__restrict__ flags) {
+  __shared__ double Dl[BCR_TAIL_BLOCKS * 64], Ll[BCR_TAIL_BLOCKS * 64], Ul[BCR_TAIL_BLOCKS * 64];
+  __shared__ double Il[BCR_TAIL_BLOCKS * 64], Fl[BCR_TAIL_BLOCKS * 8], Xl[BCR_TAIL_BLOCKS * 8];
   __shared__ double smem[16 * BCR_SCRATCH];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double *sm = smem + wave * BCR_SCRATCH;
+  const int nc = (nb + s0 - 1) / s0;  // compact block count (<= BCR_TAIL_BLOCKS)
+  for (int p = tid; p < nc * 64; p += 1024) {
+    const int64_t g = (int64_t)(p >> 6) * s0 * 64 + (p & 63);
+    Dl[p] = D[g];
+    Ll[p] = L[g];
+    Ul[p] = U[g];
+  }
+  for (int p = tid; p < nc * 8; p += 1024) Fl[p] = F[(int64_t)(p >> 3) * s0 * 8 + (p & 7)];
+  __syncthreads();
   int top = 0;
-  for (int st = s0; st < nb; st *= 2) {
-    const int ne = (nb - st + 2 * st - 1) / (2 * st);
-    for (int e = wave; e < ne; e += 16) bcr_invert_block(D, Dinv, st + e * 2 * st, lane, sm, flags);
+  for (int st = 1; st < nc; st *= 2) {
+    const int ne = (nc - st + 2 * st - 1) / (2 * st);
+    for (int e = wave; e < ne; e += 16) bcr_invert_block(Dl, Il, st + e * 2 * st, lane, sm, flags);
     __syncthreads();
-    const int nk = (nb + 2 * st - 1) / (2 * st);
-    for (int k = wave; k < nk; k += 16) bcr_reduce_block(D, L, U, F, Dinv, nb, st, k * 2 * st, lane, sm);
+    const int nk = (nc + 2 * st - 1) / (2 * st);
+    for (int k = wave; k < nk; k += 16)
+      bcr_reduce_block(Dl, Ll, Ul, Fl, Il, nc, st, k * 2 * st, lane, sm);
     __syncthreads();
     top = st;
   }
   if (wave == 0) {
-    bcr_invert_block(D, Dinv, 0, lane, sm, flags);
-    bcr_back_block(Dinv, L, U, F, X, nb, 0, 0, lane, sm);
+    bcr_invert_block(Dl, Il, 0, lane, sm, flags);
+    bcr_back_block(Il, Ll, Ul, Fl, Xl, nc, 0, 0, lane, sm);
   }
   __syncthreads();
-  for (int st = top; st >= s0 && st >= 1; st /= 2) {
-    const int ne = (nb - st + 2 * st - 1) / (2 * st);
+  for (int st = top; st >= 1; st /= 2) {
+    const int ne = (nc - st + 2 * st - 1) / (2 * st);
     for (int e = wave; e < ne; e += 16)
-      bcr_back_block(Dinv, L, U, F, X, nb, st, st + e * 2 * st, lane, sm);
+      bcr_back_block(Il, Ll, Ul, Fl, Xl, nc, st, st + e * 2 * st, lane, sm);
     __syncthreads();
   }
+  for (int p = tid; p < nc * 8; p += 1024) X[(int64_t)(p >> 3) * s0 * 8 + (p & 7)] = Xl[p];
 }
 
 __global__ void k_bcr_scatter(const double *__restrict__ X, double *__restrict__ out, int N) {
@@ -625,12 +644,11 @@ void sp_launch_bcr_solve(hipStream_t s, const SparseDev &sp, int N, int *flags) 
   hipLaunchKernelGGL(k_bcr_extract, dim3(nb), dim3(64), 0, s, sp.band, sp.ldb, sp.bw, sp.brhs, N, nb,
                      sp.bD, sp.bL, sp.bU, sp.bF);
   // levels with many blocks: one workgroup per block; from the first level with at most
-  // BCR_TAIL_BLOCKS blocks left: everything in one workgroup (PGF_BCR_TAIL=0 disables)
-  static const bool use_tail = !(getenv("PGF_BCR_TAIL") && atoi(getenv("PGF_BCR_TAIL")) == 0);
+  // BCR_TAIL_BLOCKS blocks left: everything in one workgroup, in LDS
   int st = 1;
   for (; st < nb; st *= 2) {
     const int left = (nb + st - 1) / st;  // blocks still in play before this level
-    if (use_tail && left <= BCR_TAIL_BLOCKS) break;
+    if (left <= BCR_TAIL_BLOCKS) break;
     const int ne = (nb - st + 2 * st - 1) / (2 * st);  // eliminated: st, 3st, ...
     if (ne > 0)
       hipLaunchKernelGGL(k_bcr_invert, dim3(ne), dim3(64), 0, s, sp.bD, sp.bDinv, nb, st, st,
@@ -640,8 +658,8 @@ void sp_launch_bcr_solve(hipStream_t s, const SparseDev &sp, int N, int *flags) 
                        nb, st);
   }
   // st: first level NOT done above (st >= nb: only the last block is left)
-  hipLaunchKernelGGL(k_bcr_tail, dim3(1), dim3(1024), 0, s, sp.bD, sp.bL, sp.bU, sp.bF, sp.bDinv,
-                     sp.bX, nb, st, flags);
+  hipLaunchKernelGGL(k_bcr_tail, dim3(1), dim3(1024), 0, s, sp.bD, sp.bL, sp.bU, sp.bF, sp.bX, nb, st,
+                     flags);
   for (int bs = st / 2; bs >= 1; bs /= 2) {
     const int ne = (nb - bs + 2 * bs - 1) / (2 * bs);
     if (ne > 0)
