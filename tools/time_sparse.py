@@ -1,0 +1,25 @@
+"""Host-side timing of the banded path's calls (diagnostic)."""
+import sys, time
+import numpy as np
+sys.path.insert(0, ".")
+import torch  # noqa
+from pygradflow_amd import problems
+from pygradflow_amd.newton import DeviceNewton
+
+m = 50000
+prob = problems.sparse_ocp(m, seed=0)
+n = prob.num_vars
+dn = DeviceNewton(prob, "Full", np.zeros(n), np.zeros(m), 1.0, 1.0)
+acc = {}
+def t(name, f):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); r = f(); torch.cuda.synchronize()
+    acc.setdefault(name, []).append(time.perf_counter() - t0); return r
+for i in range(30):
+    if i % 2 == 0 and i > 0:
+        t("advance", dn.advance_outer)
+    t("step_async", dn.step_async)
+    t("sync", dn.sync)
+    t("resnorm", dn.residual_norm)
+for k, v in acc.items():
+    print(k, "median us", 1e6 * float(np.median(v)), "max", 1e6 * max(v))
