@@ -15,7 +15,8 @@ def t(name, f):
     torch.cuda.synchronize()
     t0 = time.perf_counter(); r = f(); torch.cuda.synchronize()
     acc.setdefault(name, []).append(time.perf_counter() - t0); return r
-for i in range(30):
+NS = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+for i in range(NS):
     if i % 2 == 0 and i > 0:
         t("advance", dn.advance_outer)
     t("step_async", dn.step_async)
@@ -23,3 +24,8 @@ for i in range(30):
     t("resnorm", dn.residual_norm)
 for k, v in acc.items():
     print(k, "median us", 1e6 * float(np.median(v)), "max", 1e6 * max(v))
+
+v = np.array(acc["step_async"]) * 1e6
+for k in range(0, len(v), 10):
+    print(k, " ".join(f"{x:7.0f}" for x in v[k:k + 10]))
+print("residual", dn.residual_norm())
