@@ -263,11 +263,17 @@ def main():
         one_step(i)
     dn.set_outer(x0, y0, 1.0, 1.0)
     fence()
+    trace = [] if os.environ.get("PGF_BENCH_TRACE") else None
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(i)
+        if trace is not None:
+            trace.append(time.perf_counter())
     fence()
     elapsed = time.perf_counter() - t0
+    if trace is not None and rank == 0:  # diagnostic: wall time of every step (us)
+        d = np.diff(np.array([t0] + trace)) * 1e6
+        print("step us:", " ".join(f"{v:.0f}" for v in d), file=sys.stderr, flush=True)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
