@@ -22,6 +22,7 @@ of the reference path, oracle/, timed on the host cores; kind "port").
 
 import argparse
 import json
+import gc
 import os
 import sys
 import time
@@ -264,6 +265,11 @@ def main():
     dn.set_outer(x0, y0, 1.0, 1.0)
     fence()
     trace = [] if os.environ.get("PGF_BENCH_TRACE") else None
+    # the CPU-baseline leg leaves garbage behind (scipy factors, per-step records); a cyclic
+    # collection in the middle of the timed loop was seen to stall ONE step by 60 ms, which
+    # matters for the sub-millisecond banded workloads
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(i)
@@ -271,6 +277,7 @@ def main():
             trace.append(time.perf_counter())
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if trace is not None and rank == 0:  # diagnostic: wall time of every step (us)
         d = np.diff(np.array([t0] + trace)) * 1e6
         print("step us:", " ".join(f"{v:.0f}" for v in d), file=sys.stderr, flush=True)
