@@ -181,7 +181,7 @@ int pgf_destroy(pgf_handle h) {
     SparseDev &sp = h->sp;
     void *sps[] = {sp.pos, sp.Hptr, sp.Hrow, sp.Hcol, sp.Hslot, sp.Jptr, sp.Jcol, sp.Jslot, sp.JTptr,
                    sp.JTrow, sp.JTmap, sp.Hval, sp.Jval, sp.band, sp.brhs, sp.Hb0, sp.Jb0,
-                   sp.bD, sp.bL, sp.bU, sp.bDinv, sp.bF, sp.bX};
+                   sp.bD, sp.bL, sp.bU, sp.bDinv, sp.bF, sp.bX, sp.bneg};
     for (void *q : sps)
       if (q) (void)hipFree(q);
   }
@@ -616,6 +616,10 @@ int pgf_sparse_set_pattern(pgf_handle h, int bw, const int *pos, int nnzH, const
       (void)hipFree(*q);
       *q = nullptr;
     }
+  if (sp.bneg) {
+    (void)hipFree(sp.bneg);
+    sp.bneg = nullptr;
+  }
   HIPCHK(h, dalloc(&sp.Hval, (size_t)nnzH));
   HIPCHK(h, dalloc(&sp.Jval, (size_t)nnzJ));
   HIPCHK(h, dalloc(&sp.band, (size_t)(N + 1) * sp.ldb));
@@ -630,6 +634,7 @@ int pgf_sparse_set_pattern(pgf_handle h, int bw, const int *pos, int nnzH, const
     HIPCHK(h, dalloc(&sp.bDinv, nbk * 64));
     HIPCHK(h, dalloc(&sp.bF, nbk * 8));
     HIPCHK(h, dalloc(&sp.bX, nbk * 8));
+    HIPCHK(h, dalloc(&sp.bneg, nbk));
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   sp.active = true;

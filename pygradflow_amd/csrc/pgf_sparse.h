@@ -18,6 +18,7 @@ struct SparseDev {
   double *Hb0 = nullptr, *Jb0 = nullptr;
   // block cyclic reduction work arrays: (N/8) blocks of 8 x 8 (D, L, U, inv D), rhs, solution
   double *bD = nullptr, *bL = nullptr, *bU = nullptr, *bDinv = nullptr, *bF = nullptr, *bX = nullptr;
+  int *bneg = nullptr;                      // negative pivots met while inverting block i
   bool values_set = false;
 };
 

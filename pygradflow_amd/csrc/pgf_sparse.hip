@@ -435,9 +435,13 @@ __device__ __forceinline__ int gj_inverse8(double *M, int lane, int *bad) {
 // large levels and by the fused tail kernel below.
 #define BCR_SCRATCH (3 * 64 + 8)
 
+// The negative-pivot count goes to negcnt[gi] (gi = the block's global index), NOT to one
+// atomic counter: in a KKT matrix nearly every block has negative pivots, and 9 375
+// workgroups adding to the same word serialised in L2 (110 us for the first level alone).
 __device__ __forceinline__ void bcr_invert_block(const double *__restrict__ D,
                                                  double *__restrict__ Dinv, int i, int lane,
-                                                 double *sm, int *__restrict__ flags) {
+                                                 double *sm, int *__restrict__ flags,
+                                                 int *__restrict__ negcnt, int gi) {
   double *M = sm;
   M[lane] = D[(int64_t)i * 64 + lane];
   int bad = 0;
@@ -445,7 +449,7 @@ __device__ __forceinline__ void bcr_invert_block(const double *__restrict__ D,
   Dinv[(int64_t)i * 64 + lane] = M[lane];
   if (lane == 0) {
     if (bad) atomicOr(&flags[0], 1);
-    if (neg) atomicAdd(&flags[1], neg);
+    negcnt[gi] = neg;
   }
 }
 
@@ -543,11 +547,12 @@ __device__ __forceinline__ void bcr_back_block(const double *__restrict__ Dinv,
 // invert the blocks eliminated at this level: i = s, 3s, 5s, ... (i mod 2s == s)
 __global__ __launch_bounds__(64) void k_bcr_invert(const double *__restrict__ D,
                                                    double *__restrict__ Dinv, int nb, int s,
-                                                   int first, int stride, int *__restrict__ flags) {
+                                                   int first, int stride, int *__restrict__ flags,
+                                                   int *__restrict__ negcnt) {
   __shared__ double sm[BCR_SCRATCH];
   const int i = first + blockIdx.x * stride;
   if (i >= nb) return;
-  bcr_invert_block(D, Dinv, i, threadIdx.x, sm, flags);
+  bcr_invert_block(D, Dinv, i, threadIdx.x, sm, flags, negcnt, i);
   (void)s;
 }
 
@@ -590,7 +595,8 @@ __global__ __launch_bounds__(1024) void k_bcr_tail(const double *__restrict__ D,
                                                    const double *__restrict__ U,
                                                    const double *__restrict__ F,
                                                    double *__restrict__ X, int nb, int s0,
-                                                   int *__restrict__ flags) {
+                                                   int *__restrict__ flags,
+                                                   int *__restrict__ negcnt) {
   __shared__ double Dl[BCR_TAIL_BLOCKS * 64], Ll[BCR_TAIL_BLOCKS * 64], Ul[BCR_TAIL_BLOCKS * 64];
   __shared__ double Il[BCR_TAIL_BLOCKS * 64], Fl[BCR_TAIL_BLOCKS * 8], Xl[BCR_TAIL_BLOCKS * 8];
   __shared__ double smem[16 * BCR_SCRATCH];
@@ -608,7 +614,10 @@ __global__ __launch_bounds__(1024) void k_bcr_tail(const double *__restrict__ D,
   int top = 0;
   for (int st = 1; st < nc; st *= 2) {
     const int ne = (nc - st + 2 * st - 1) / (2 * st);
-    for (int e = wave; e < ne; e += 16) bcr_invert_block(Dl, Il, st + e * 2 * st, lane, sm, flags);
+    for (int e = wave; e < ne; e += 16) {
+      const int j = st + e * 2 * st;
+      bcr_invert_block(Dl, Il, j, lane, sm, flags, negcnt, j * s0);
+    }
     __syncthreads();
     const int nk = (nc + 2 * st - 1) / (2 * st);
     for (int k = wave; k < nk; k += 16)
@@ -617,7 +626,7 @@ __global__ __launch_bounds__(1024) void k_bcr_tail(const double *__restrict__ D,
     top = st;
   }
   if (wave == 0) {
-    bcr_invert_block(Dl, Il, 0, lane, sm, flags);
+    bcr_invert_block(Dl, Il, 0, lane, sm, flags, negcnt, 0);
     bcr_back_block(Il, Ll, Ul, Fl, Xl, nc, 0, 0, lane, sm);
   }
   __syncthreads();
@@ -628,6 +637,19 @@ __global__ __launch_bounds__(1024) void k_bcr_tail(const double *__restrict__ D,
     __syncthreads();
   }
   for (int p = tid; p < nc * 8; p += 1024) X[(int64_t)(p >> 3) * s0 * 8 + (p & 7)] = Xl[p];
+  // inertia: every block has been inverted exactly once by now (earlier launches or above)
+  __shared__ int part[16];
+  int cnt = 0;
+  for (int i = tid; i < nb; i += 1024) cnt += negcnt[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+  if (lane == 0) part[wave] = cnt;
+  __syncthreads();
+  if (tid == 0) {
+    int tot = 0;
+    for (int w = 0; w < 16; ++w) tot += part[w];
+    flags[1] = tot;
+  }
 }
 
 __global__ void k_bcr_scatter(const double *__restrict__ X, double *__restrict__ out, int N) {
@@ -652,14 +674,14 @@ void sp_launch_bcr_solve(hipStream_t s, const SparseDev &sp, int N, int *flags) 
     const int ne = (nb - st + 2 * st - 1) / (2 * st);  // eliminated: st, 3st, ...
     if (ne > 0)
       hipLaunchKernelGGL(k_bcr_invert, dim3(ne), dim3(64), 0, s, sp.bD, sp.bDinv, nb, st, st,
-                         2 * st, flags);
+                         2 * st, flags, sp.bneg);
     const int nk = (nb + 2 * st - 1) / (2 * st);       // kept: 0, 2st, ...
     hipLaunchKernelGGL(k_bcr_reduce, dim3(nk), dim3(64), 0, s, sp.bD, sp.bL, sp.bU, sp.bF, sp.bDinv,
                        nb, st);
   }
   // st: first level NOT done above (st >= nb: only the last block is left)
   hipLaunchKernelGGL(k_bcr_tail, dim3(1), dim3(1024), 0, s, sp.bD, sp.bL, sp.bU, sp.bF, sp.bX, nb, st,
-                     flags);
+                     flags, sp.bneg);
   for (int bs = st / 2; bs >= 1; bs /= 2) {
     const int ne = (nb - bs + 2 * bs - 1) / (2 * bs);
     if (ne > 0)
