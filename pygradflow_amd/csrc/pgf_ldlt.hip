@@ -157,9 +157,47 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
   }
   __syncthreads();
 
+  // (c) of sub-block `psb`: M[ti][tj] -= W[ti] L[tj]^T for tj in (psb, 3], ti in [tj, 7].
+  // The tile the next diagonal factorisation needs, (psb+1, psb+1), is "urgent"; the others
+  // are done by wavefronts 1..3 WHILE wavefront 0 factorises the next diagonal tile.
+  auto update_tile16 = [&](int psb, int ti, int tj) {
+    const int pcb = psb * 16;
+    double4_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = M[ti * 16 + l4 + 4 * r][tj * 16 + l15];
+#pragma unroll
+    for (int ks = 0; ks < 16; ks += 4) {
+      const double av = -Wt[ti * 16 + l15][ks + l4];
+      const double bv = M[tj * 16 + l15][pcb + ks + l4];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) M[ti * 16 + l4 + 4 * r][tj * 16 + l15] = acc[r];
+  };
+  auto update_rest = [&](int psb) {  // all tiles of step psb except the urgent one; waves 1..3
+    int total = 0;
+    for (int tj = psb + 1; tj < 4; ++tj) total += 8 - tj;
+    for (int e0 = wave; e0 < total; e0 += 3) {  // e0 = 0 is the urgent tile: wave 0 skips it all
+      int e = e0, tj = psb + 1;
+      while (e >= 8 - tj) {
+        e -= 8 - tj;
+        ++tj;
+      }
+      update_tile16(psb, tj + e, tj);
+    }
+  };
+
   for (int sb = 0; sb < 4; ++sb) {
     const int cb = sb * 16;
-    // ---- (a) factor the 16 x 16 diagonal tile: wavefront 0, lane (l & 15) <-> row
+    // ---- phase 1: wavefront 0: urgent tile of the previous step, then (a) factor the
+    // 16 x 16 diagonal tile (lane (l & 15) <-> row); wavefronts 1..3: rest of (c) of the
+    // previous step
+    if (sb > 0 && !(skip & 4)) {
+      if (wave == 0)
+        update_tile16(sb - 1, sb, sb);
+      else
+        update_rest(sb - 1);
+    }
     if (wave == 0 && !(skip & 1)) {
       double a[16];
 #pragma unroll
@@ -192,7 +230,7 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
       }
     }
     __syncthreads();
-    // ---- (b) rows below the tile: substitution, one lane per row (wavefronts 0 and 1)
+    // ---- phase 2 (b): rows below the tile: substitution, one lane per row (wavefronts 0, 1)
     if (wave < 2 && !(skip & 2)) {
       const int row = cb + 16 + wave * 64 + lane;
       if (row < 128) {
@@ -235,31 +273,6 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
       }
     }
     __syncthreads();
-    // ---- (c) tiles to the right: M[ti][tj] -= W[ti] L[tj]^T, tj in (sb, 3], ti in [tj, 7]
-    if (sb < 3 && !(skip & 4)) {
-      int total = 0;
-      for (int tj = sb + 1; tj < 4; ++tj) total += 8 - tj;
-      for (int e0 = wave; e0 < total; e0 += 4) {
-        int e = e0, tj = sb + 1;
-        while (e >= 8 - tj) {
-          e -= 8 - tj;
-          ++tj;
-        }
-        const int ti = tj + e;
-        double4_t acc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = M[ti * 16 + l4 + 4 * r][tj * 16 + l15];
-#pragma unroll
-        for (int ks = 0; ks < 16; ks += 4) {
-          const double av = -Wt[ti * 16 + l15][ks + l4];
-          const double bv = M[tj * 16 + l15][cb + ks + l4];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) M[ti * 16 + l4 + 4 * r][tj * 16 + l15] = acc[r];
-      }
-      __syncthreads();
-    }
   }
 
   // ---- write back: own rows (L), and by workgroup 0 the factored diagonal block
