@@ -319,6 +319,26 @@ def main():
                 factor_ms_per_step=pr["factor_ms"] / args.steps,
             )
 
+    # SURVEY.md 8d "reported separately": the back-solve step of the Simplified policy
+    # (2nd+ Newton step of an outer iteration: residual, reduced rhs, forward + backward
+    # triangular solves, update -- no assembly, no factorisation).  Outside the timed region.
+    backsolve = None
+    if rank == 0 and world == 1:
+        dn.close()
+        ds = DeviceNewton(problem, "Simplified", x0, y0, 1.0, 1.0, device=local_rank)
+        ds.step()  # factorises
+        for _ in range(3):
+            ds.step()
+        torch.cuda.synchronize(dev)
+        tb = time.perf_counter()
+        nbs = max(10, args.steps)
+        for _ in range(nbs):
+            ds.step()
+        torch.cuda.synchronize(dev)
+        bms = 1e3 * (time.perf_counter() - tb) / nbs
+        backsolve = dict(ms_per_step=bms, steps_per_s=1e3 / bms, steps=nbs)
+        dn = ds
+
     if rank == 0:
         total_steps = args.steps * world
         out = {
@@ -343,6 +363,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "parity": parity,
+            "backsolve_step": backsolve,
         }
         print(json.dumps(out), flush=True)
     dn.close()
