@@ -1601,12 +1601,17 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
   // wrong factors, periodic in 8 workgroups).  An explicit record + wait on the same stream
   // between dependent launches restores the in-order semantics; without look-ahead (one
   // queue) it is not needed.
+  auto fence_on = [&](hipStream_t st) {
+    hipEvent_t ev = next_event();
+    (void)hipEventRecord(ev, st);
+    (void)hipStreamWaitEvent(st, ev, 0);
+  };
+  // PGF_LA_DEBUG: 9 = no extra fences at all, 10 = only at the cross-queue edges
   auto self_fence = [&]() {
-    if (la && la_dbg != 9) {
-      hipEvent_t ev = next_event();
-      (void)hipEventRecord(ev, sA);
-      (void)hipStreamWaitEvent(sA, ev, 0);
-    }
+    if (la && la_dbg != 9 && la_dbg != 10) fence_on(sA);
+  };
+  auto edge_fence = [&](hipStream_t st) {
+    if (la && la_dbg == 10) fence_on(st);
   };
   const int skip = (getenv("PGF_SKIP") ? atoi(getenv("PGF_SKIP")) : 0) | (cohA << 3);
   // filler tiles in the panel launches: correct, but not yet a win (the panel's 87 KB of
@@ -1686,7 +1691,10 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
         launch_update(f, sA, Wb, OB, N, nrows, obEnd, obEnd, N, ob0, KB, p, 0);
         continue;
       }
-      if (la && b_pending) (void)hipStreamWaitEvent(sA, ev_b_done, 0);  // RMW order
+      if (la && b_pending) {
+        (void)hipStreamWaitEvent(sA, ev_b_done, 0);  // RMW order
+        edge_fence(sA);
+      }
       launch_update(f, sA, Wb, OB, N, nrows, obEnd, obEnd, nextEnd, ob0, KB, p, cohA);
       self_fence();
       if (nextEnd < N) {
@@ -1694,6 +1702,7 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
           hipEvent_t ev_a = next_event();
           (void)hipEventRecord(ev_a, sA);
           (void)hipStreamWaitEvent(sB, ev_a, 0);
+          edge_fence(sB);
           launch_update(f, sB, Wb, OB, N, nrows, nextEnd, nextEnd, N, ob0, KB, p, cohB);
           ev_b_done = next_event();
           (void)hipEventRecord(ev_b_done, sB);
@@ -1713,7 +1722,10 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
       }
     }
   }
-  if (la && b_pending) (void)hipStreamWaitEvent(sA, ev_b_done, 0);
+  if (la && b_pending) {
+    (void)hipStreamWaitEvent(sA, ev_b_done, 0);
+    edge_fence(sA);
+  }
   self_fence();
   if (N > 0)
     hipLaunchKernelGGL(k_inv_diag_blocks, dim3((N + 63) / 64), dim3(64), 0, sA, f.K, f.ldk, N,
