@@ -1573,7 +1573,9 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
   const bool la = getenv("PGF_LOOKAHEAD") != nullptr;
   const int cohm = getenv("PGF_COHERENT") ? atoi(getenv("PGF_COHERENT")) : 0;
   const int cohA = cohm & 1, cohB = (cohm >> 1) & 1;
-  hipStream_t sB = la ? f.stream2 : f.stream;
+  // PGF_LA_ONEQ: the look-ahead launch sequence on ONE queue (separates schedule logic from
+  // multi-queue effects)
+  hipStream_t sB = (la && !getenv("PGF_LA_ONEQ")) ? f.stream2 : f.stream;
   int evi = 0;
   auto next_event = [&]() -> hipEvent_t {
     if ((size_t)evi >= f.ev_ring.size()) {
