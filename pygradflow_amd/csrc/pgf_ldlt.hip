@@ -1463,14 +1463,21 @@ hipError_t ldlt_alloc(DenseLdlt &f, int Nmax, hipStream_t stream) {
   f.stream = stream;
   hipError_t e;
   const size_t rows = (size_t)Nmax + 1 + PGF_NB;
-  if ((e = hipMalloc(&f.K, rows * f.ldk * sizeof(double))) != hipSuccess) return e;
+  // PGF_FINEGRAINED=1 (diagnostic): K and W in fine-grained device memory, i.e. coherent
+  // across the XCDs' L2s without kernel-boundary cache maintenance
+  const bool fg = getenv("PGF_FINEGRAINED") != nullptr;
+  auto dmalloc = [&](double **ptr, size_t bytes) {
+    return fg ? hipExtMallocWithFlags((void **)ptr, bytes, hipDeviceMallocFinegrained)
+              : hipMalloc((void **)ptr, bytes);
+  };
+  if ((e = dmalloc(&f.K, rows * f.ldk * sizeof(double))) != hipSuccess) return e;
   f.OB = 256;
   if (const char *ob = getenv("PGF_OB")) {
     const int v = atoi(ob);
     if (v == 64 || v == 128 || v == 192 || v == 256) f.OB = v;
   }
   f.wstride = rows * (size_t)f.OB;
-  if ((e = hipMalloc(&f.W, 2 * f.wstride * sizeof(double))) != hipSuccess) return e;
+  if ((e = dmalloc(&f.W, 2 * f.wstride * sizeof(double))) != hipSuccess) return e;
   if ((e = hipStreamCreateWithFlags(&f.stream2, hipStreamNonBlocking)) != hipSuccess) return e;
   if ((e = hipEventCreateWithFlags(&f.ev_panel, hipEventDisableTiming)) != hipSuccess) return e;
   if ((e = hipEventCreateWithFlags(&f.ev_update, hipEventDisableTiming)) != hipSuccess) return e;
@@ -1865,7 +1872,14 @@ hipError_t ldlt_bench_update(int N, int KB, int variant, int reps, double *ms_ou
   f.ldk = pick_ldk(N + KB);
   f.stream = s;
   const size_t rows = (size_t)N + KB + 1;
-  if ((e = hipMalloc(&f.K, rows * f.ldk * sizeof(double))) != hipSuccess) return e;
+  // PGF_FINEGRAINED=1 (diagnostic): K and W in fine-grained device memory, i.e. coherent
+  // across the XCDs' L2s without kernel-boundary cache maintenance
+  const bool fg = getenv("PGF_FINEGRAINED") != nullptr;
+  auto dmalloc = [&](double **ptr, size_t bytes) {
+    return fg ? hipExtMallocWithFlags((void **)ptr, bytes, hipDeviceMallocFinegrained)
+              : hipMalloc((void **)ptr, bytes);
+  };
+  if ((e = dmalloc(&f.K, rows * f.ldk * sizeof(double))) != hipSuccess) return e;
   if ((e = hipMalloc(&f.W, rows * KB * sizeof(double))) != hipSuccess) return e;
   hipLaunchKernelGGL(k_fill_pattern, dim3((rows * f.ldk + 255) / 256), dim3(256), 0, s, f.K,
                      rows * f.ldk, 1.0);
