@@ -157,10 +157,17 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
   }
   __syncthreads();
 
-  // (c) of sub-block `psb`: M[ti][tj] -= W[ti] L[tj]^T for tj in (psb, 3], ti in [tj, 7].
-  // The tile the next diagonal factorisation needs, (psb+1, psb+1), is "urgent"; the others
-  // are done by wavefronts 1..3 WHILE wavefront 0 factorises the next diagonal tile.
-  auto update_tile16 = [&](int psb, int ti, int tj) {
+  // Schedule of one 16-column sub-block `sb` (cb = 16 sb).  Critical path = wavefront 0:
+  //   (a+) wavefront 0, lane <-> row of the 64 x 64 DIAGONAL block: right-looking elimination
+  //        of the 16 columns for the tile rows AND, in the same instruction stream, for all
+  //        diagonal-block rows below the tile (their W = L D and L come for free);
+  //   (c-diag) rank-16 update of the diagonal block's remaining tiles (MFMA);
+  // off the critical path, one step behind, for the workgroup's OWN 64 rows (stack rows
+  // 64..127): (b-own) substitution by wavefront 1 while wavefront 0 runs the next (a+);
+  // (c-own) their tile updates alongside (c-diag).
+  // The earlier version substituted all 112 rows below the tile between (a) and (c): 1.4 us
+  // per sub-block on the critical path.
+  auto update_tile16 = [&](int psb, int ti, int tj) {  // M[ti][tj] -= W_psb[ti] L_psb[tj]^T
     const int pcb = psb * 16;
     double4_t acc;
 #pragma unroll
@@ -174,106 +181,124 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
 #pragma unroll
     for (int r = 0; r < 4; ++r) M[ti * 16 + l4 + 4 * r][tj * 16 + l15] = acc[r];
   };
-  auto update_rest = [&](int psb) {  // all tiles of step psb except the urgent one; waves 1..3
-    int total = 0;
-    for (int tj = psb + 1; tj < 4; ++tj) total += 8 - tj;
-    for (int e0 = wave; e0 < total; e0 += 3) {  // e0 = 0 is the urgent tile: wave 0 skips it all
-      int e = e0, tj = psb + 1;
-      while (e >= 8 - tj) {
-        e -= 8 - tj;
-        ++tj;
+  auto a_plus = [&](int sb) {  // wavefront 0
+    const int cb = sb * 16;
+    double a[16], w[16];
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+      const double2_t v = *reinterpret_cast<const double2_t *>(&M[lane][cb + k]);
+      a[k] = v.x;
+      a[k + 1] = v.y;
+    }
+    double d_mine = 1.0, di_mine = 1.0;
+    int bad_any = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const double d = lane_bcast(a[j], cb + j);
+      const bool bad = (d == 0.0) || !(fabs(d) <= 1.79e308);
+      const double di = bad ? 0.0 : fast_recip(d);
+      bad_any |= (bad && (cb + j) < nb) ? 1 : 0;
+      if (lane == cb + j) {
+        d_mine = d;
+        di_mine = di;
       }
-      update_tile16(psb, tj + e, tj);
+      w[j] = a[j];
+      const double l = a[j] * di;
+#pragma unroll
+      for (int k = j + 1; k < 16; ++k) a[k] = fma(-l, lane_bcast(a[j], cb + k), a[k]);
+      a[j] = l;
+    }
+    const int tr = lane - cb;  // row inside the tile (tile lanes: 0..15)
+    if (tr >= 0 && tr < 16) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (k < tr) M[lane][cb + k] = a[k];
+      M[lane][lane] = d_mine;
+      dD[lane] = d_mine;
+      dI[lane] = di_mine;
+      if (tr == 0 && bad_any) s_bad = 1;
+    } else if (tr >= 16) {  // diagonal-block rows below the tile
+#pragma unroll
+      for (int k = 0; k < 16; k += 2) {
+        double2_t wv, lv;
+        wv.x = w[k];
+        wv.y = w[k + 1];
+        lv.x = a[k];
+        lv.y = a[k + 1];
+        *reinterpret_cast<double2_t *>(&Wt[lane][k]) = wv;
+        *reinterpret_cast<double2_t *>(&M[lane][cb + k]) = lv;
+      }
+    }
+  };
+  auto b_own = [&](int sb) {  // wavefront 1: substitution for the own rows, one lane per row
+    const int cb = sb * 16;
+    const int row = 64 + lane;
+    double x[16];
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+      const double2_t v = *reinterpret_cast<const double2_t *>(&M[row][cb + k]);
+      x[k] = v.x;
+      x[k + 1] = v.y;
+    }
+#pragma unroll
+    for (int t = 0; t < 15; ++t) {
+      const double xt = x[t];
+#pragma unroll
+      for (int j = t + 1; j < 16; ++j) x[j] = fma(-xt, M[cb + j][cb + t], x[j]);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+      double2_t wv, lv;
+      wv.x = x[k];
+      wv.y = x[k + 1];
+      lv.x = x[k] * dI[cb + k];
+      lv.y = x[k + 1] * dI[cb + k + 1];
+      *reinterpret_cast<double2_t *>(&Wt[row][k]) = wv;
+      *reinterpret_cast<double2_t *>(&M[row][cb + k]) = lv;
+    }
+    const int r = rbase + lane;
+    if (r < nrows) {
+      double *wp = W + (int64_t)r * ldw + wofs + cb;
+#pragma unroll
+      for (int k = 0; k < 16; k += 2) {
+        double2_t wv;
+        wv.x = x[k];
+        wv.y = x[k + 1];
+        st_f64x2(wp + k, wv, coh);
+      }
+    }
+  };
+  // tiles of phase 2 of sub-block sb, numbered: first (c-diag) of step sb: tj in (sb, 3],
+  // ti in [tj, 3]; then (c-own) of step sb - 1: tj in (sb - 1, 3], ti in [4, 7]
+  auto phase2 = [&](int sb) {
+    const int nd = (3 - sb) * (4 - sb) / 2;
+    const int no = sb > 0 ? 4 * (4 - sb) : 0;
+    for (int e0 = wave; e0 < nd + no; e0 += 4) {
+      if (e0 < nd) {
+        int e = e0, tj = sb + 1;
+        while (e >= 4 - tj) {
+          e -= 4 - tj;
+          ++tj;
+        }
+        update_tile16(sb, tj + e, tj);
+      } else {
+        const int e = e0 - nd;
+        update_tile16(sb - 1, 4 + (e & 3), sb + (e >> 2));
+      }
     }
   };
 
   for (int sb = 0; sb < 4; ++sb) {
-    const int cb = sb * 16;
-    // ---- phase 1: wavefront 0: urgent tile of the previous step, then (a) factor the
-    // 16 x 16 diagonal tile (lane (l & 15) <-> row); wavefronts 1..3: rest of (c) of the
-    // previous step
-    if (sb > 0 && !(skip & 4)) {
-      if (wave == 0)
-        update_tile16(sb - 1, sb, sb);
-      else
-        update_rest(sb - 1);
-    }
-    if (wave == 0 && !(skip & 1)) {
-      double a[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) a[k] = M[cb + l15][cb + k];
-      double d_mine = 1.0, di_mine = 1.0;
-      int bad_any = 0;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const double d = lane_bcast(a[j], j);
-        const bool bad = (d == 0.0) || !(fabs(d) <= 1.79e308);
-        const double di = bad ? 0.0 : fast_recip(d);
-        bad_any |= (bad && (cb + j) < nb) ? 1 : 0;
-        if (l15 == j) {
-          d_mine = d;
-          di_mine = di;
-        }
-        const double l = a[j] * di;
-#pragma unroll
-        for (int k = j + 1; k < 16; ++k) a[k] = fma(-l, lane_bcast(a[j], k), a[k]);
-        a[j] = l;
-      }
-      if (lane < 16) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-          if (k < lane) M[cb + lane][cb + k] = a[k];
-        M[cb + lane][cb + lane] = d_mine;
-        dD[cb + lane] = d_mine;
-        dI[cb + lane] = di_mine;
-        if (lane == 0 && bad_any) s_bad = 1;
-      }
-    }
+    // phase 1: (a+) of this step beside (b-own) of the previous one
+    if (wave == 0 && !(skip & 1)) a_plus(sb);
+    if (wave == 1 && sb > 0 && !(skip & 2)) b_own(sb - 1);
     __syncthreads();
-    // ---- phase 2 (b): rows below the tile: substitution, one lane per row (wavefronts 0, 1)
-    if (wave < 2 && !(skip & 2)) {
-      const int row = cb + 16 + wave * 64 + lane;
-      if (row < 128) {
-        double x[16];
-#pragma unroll
-        for (int k = 0; k < 16; k += 2) {
-          const double2_t v = *reinterpret_cast<const double2_t *>(&M[row][cb + k]);
-          x[k] = v.x;
-          x[k + 1] = v.y;
-        }
-#pragma unroll
-        for (int t = 0; t < 15; ++t) {
-          const double xt = x[t];
-#pragma unroll
-          for (int j = t + 1; j < 16; ++j) x[j] = fma(-xt, M[cb + j][cb + t], x[j]);
-        }
-#pragma unroll
-        for (int k = 0; k < 16; k += 2) {
-          double2_t w, l;
-          w.x = x[k];
-          w.y = x[k + 1];
-          l.x = x[k] * dI[cb + k];
-          l.y = x[k + 1] * dI[cb + k + 1];
-          *reinterpret_cast<double2_t *>(&Wt[row][k]) = w;
-          *reinterpret_cast<double2_t *>(&M[row][cb + k]) = l;
-        }
-        if (row >= 64) {
-          const int r = rbase + row - 64;
-          if (r < nrows) {
-            double *wp = W + (int64_t)r * ldw + wofs + cb;
-#pragma unroll
-            for (int k = 0; k < 16; k += 2) {
-              double2_t w;
-              w.x = x[k];
-              w.y = x[k + 1];
-              st_f64x2(wp + k, w, coh);
-            }
-          }
-        }
-      }
-    }
+    // phase 2: (c-diag) of this step, (c-own) of the previous one
+    if (!(skip & 4)) phase2(sb);
     __syncthreads();
   }
+  if (wave == 1 && !(skip & 2)) b_own(3);  // no tiles are left to update after the last step
+  __syncthreads();
 
   // ---- write back: own rows (L), and by workgroup 0 the factored diagonal block
   for (int p = tid; p < 64 * 32; p += 256) {
