@@ -167,6 +167,20 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
   // (c-own) their tile updates alongside (c-diag).
   // The earlier version substituted all 112 rows below the tile between (a) and (c): 1.4 us
   // per sub-block on the critical path.
+  auto update_tile16 = [&](int psb, int ti, int tj) {  // M[ti][tj] -= W_psb[ti] L_psb[tj]^T
+    const int pcb = psb * 16;
+    double4_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = M[ti * 16 + l4 + 4 * r][tj * 16 + l15];
+#pragma unroll
+    for (int ks = 0; ks < 16; ks += 4) {
+      const double av = -Wt[ti * 16 + l15][ks + l4];
+      const double bv = M[tj * 16 + l15][pcb + ks + l4];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) M[ti * 16 + l4 + 4 * r][tj * 16 + l15] = acc[r];
+  };
   auto a_plus = [&](int sb) {  // wavefront 0
     const int cb = sb * 16;
     double a[16], w[16];
@@ -255,56 +269,23 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
     }
   };
   // tiles of phase 2 of sub-block sb, numbered: first (c-diag) of step sb: tj in (sb, 3],
-  // ti in [tj, 3]; then (c-own) of step sb - 1: tj in (sb - 1, 3], ti in [4, 7].  A wavefront
-  // takes tiles e0 = wave, wave + 4, ... (at most 4) and works on all of them at once: the
-  // tiles are independent, so their LDS reads and MFMA chains interleave instead of running
-  // one latency-bound chain after the other.
+  // ti in [tj, 3]; then (c-own) of step sb - 1: tj in (sb - 1, 3], ti in [4, 7]
   auto phase2 = [&](int sb) {
     const int nd = (3 - sb) * (4 - sb) / 2;
     const int no = sb > 0 ? 4 * (4 - sb) : 0;
-    int ps[4], ti[4], tj[4];
-    bool ok[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int e0 = wave + 4 * q;
-      ok[q] = e0 < nd + no;
-      ps[q] = sb;
-      ti[q] = 0;
-      tj[q] = 0;
+    for (int e0 = wave; e0 < nd + no; e0 += 4) {
       if (e0 < nd) {
-        int e = e0, t = sb + 1;
-        while (e >= 4 - t) {
-          e -= 4 - t;
-          ++t;
+        int e = e0, tj = sb + 1;
+        while (e >= 4 - tj) {
+          e -= 4 - tj;
+          ++tj;
         }
-        ti[q] = t + e;
-        tj[q] = t;
-      } else if (ok[q]) {
+        update_tile16(sb, tj + e, tj);
+      } else {
         const int e = e0 - nd;
-        ps[q] = sb - 1;
-        ti[q] = 4 + (e & 3);
-        tj[q] = sb + (e >> 2);
+        update_tile16(sb - 1, 4 + (e & 3), sb + (e >> 2));
       }
     }
-    double4_t acc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        acc[q][r] = ok[q] ? M[ti[q] * 16 + l4 + 4 * r][tj[q] * 16 + l15] : 0.0;
-#pragma unroll
-    for (int ks = 0; ks < 16; ks += 4)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double av = ok[q] ? -Wt[ti[q] * 16 + l15][ks + l4] : 0.0;
-        const double bv = ok[q] ? M[tj[q] * 16 + l15][ps[q] * 16 + ks + l4] : 0.0;
-        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[q], 0, 0, 0);
-      }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (ok[q])
-#pragma unroll
-        for (int r = 0; r < 4; ++r) M[ti[q] * 16 + l4 + 4 * r][tj[q] * 16 + l15] = acc[q][r];
   };
 
   for (int sb = 0; sb < 4; ++sb) {
