@@ -98,7 +98,9 @@ __device__ __forceinline__ double fast_recip(double d) {
 #define PNL_LD 66   // LDS row stride of M: conflict-free MFMA fragment reads, 16 B rows
 #define PNL_WLD 18
 
-#define PNL_SMEM (128 * PNL_LD * 8 + 128 * PNL_WLD * 8 + 2 * 64 * 8 + 16)
+// M[128][PNL_LD]; Wt[192][PNL_WLD]: rows 0..63 diagonal block, 64..127 / 128..191 the own
+// rows' W of even / odd sub-block steps (double buffered); D, 1/D; flag
+#define PNL_SMEM (128 * PNL_LD * 8 + 192 * PNL_WLD * 8 + 2 * 64 * 8 + 16)
 
 template <int NB, bool PRE = false>
 __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
@@ -110,7 +112,7 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
   static_assert(NB == 64, "panel kernel is written for 64-column panels");
   double(*M)[PNL_LD] = reinterpret_cast<double(*)[PNL_LD]>(smem);
   double(*Wt)[PNL_WLD] = reinterpret_cast<double(*)[PNL_WLD]>(smem + 128 * PNL_LD * 8);
-  double *dD = reinterpret_cast<double *>(smem + 128 * PNL_LD * 8 + 128 * PNL_WLD * 8);
+  double *dD = reinterpret_cast<double *>(smem + 128 * PNL_LD * 8 + 192 * PNL_WLD * 8);
   double *dI = dD + 64;
   int &s_bad = *reinterpret_cast<int *>(dI + 64);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -169,12 +171,13 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
   // per sub-block on the critical path.
   auto update_tile16 = [&](int psb, int ti, int tj) {  // M[ti][tj] -= W_psb[ti] L_psb[tj]^T
     const int pcb = psb * 16;
+    const int wrow = ti * 16 + ((ti >= 4) ? 64 * (psb & 1) : 0);  // own rows: buffer of step psb
     double4_t acc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = M[ti * 16 + l4 + 4 * r][tj * 16 + l15];
 #pragma unroll
     for (int ks = 0; ks < 16; ks += 4) {
-      const double av = -Wt[ti * 16 + l15][ks + l4];
+      const double av = -Wt[wrow + l15][ks + l4];
       const double bv = M[tj * 16 + l15][pcb + ks + l4];
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
     }
@@ -253,7 +256,7 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
       wv.y = x[k + 1];
       lv.x = x[k] * dI[cb + k];
       lv.y = x[k + 1] * dI[cb + k + 1];
-      *reinterpret_cast<double2_t *>(&Wt[row][k]) = wv;
+      *reinterpret_cast<double2_t *>(&Wt[row + 64 * (sb & 1)][k]) = wv;
       *reinterpret_cast<double2_t *>(&M[row][cb + k]) = lv;
     }
     const int r = rbase + lane;
@@ -268,11 +271,11 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
       }
     }
   };
-  // tiles of phase 2 of sub-block sb, numbered: first (c-diag) of step sb: tj in (sb, 3],
-  // ti in [tj, 3]; then (c-own) of step sb - 1: tj in (sb - 1, 3], ti in [4, 7]
+  // phase 2 of sub-block sb: (c-diag) of step sb: tj in (sb, 3], ti in [tj, 3]; then the part
+  // of (c-own) of step sb - 1 that the next (b-own) needs: column block tj = sb, ti in [4, 7]
   auto phase2 = [&](int sb) {
     const int nd = (3 - sb) * (4 - sb) / 2;
-    const int no = sb > 0 ? 4 * (4 - sb) : 0;
+    const int no = sb > 0 ? 4 : 0;
     for (int e0 = wave; e0 < nd + no; e0 += 4) {
       if (e0 < nd) {
         int e = e0, tj = sb + 1;
@@ -282,18 +285,25 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
         }
         update_tile16(sb, tj + e, tj);
       } else {
-        const int e = e0 - nd;
-        update_tile16(sb - 1, 4 + (e & 3), sb + (e >> 2));
+        update_tile16(sb - 1, 4 + (e0 - nd), sb);
       }
     }
   };
+  // the rest of (c-own) of step sb - 2 (column blocks tj in [sb, 3]): wavefronts 2, 3 during
+  // phase 1 of sub-block sb; its W sits in the other own-row buffer than the one (b-own) of
+  // step sb - 1 is writing
+  auto own_deferred = [&](int sb) {
+    const int cnt = 4 * (4 - sb);
+    for (int e = wave - 2; e < cnt; e += 2) update_tile16(sb - 2, 4 + (e & 3), sb + (e >> 2));
+  };
 
   for (int sb = 0; sb < 4; ++sb) {
-    // phase 1: (a+) of this step beside (b-own) of the previous one
+    // phase 1: (a+) of this step | (b-own) of the previous one | deferred (c-own) tiles
     if (wave == 0 && !(skip & 1)) a_plus(sb);
     if (wave == 1 && sb > 0 && !(skip & 2)) b_own(sb - 1);
+    if (wave >= 2 && sb >= 2 && !(skip & 4)) own_deferred(sb);
     __syncthreads();
-    // phase 2: (c-diag) of this step, (c-own) of the previous one
+    // phase 2: (c-diag) of this step, urgent (c-own) column of the previous one
     if (!(skip & 4)) phase2(sb);
     __syncthreads();
   }
