@@ -193,18 +193,18 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
       a[k] = v.x;
       a[k + 1] = v.y;
     }
-    double d_mine = 1.0, di_mine = 1.0;
-    int bad_any = 0;
+    // Per column the wavefront issues ~35 dependent instructions, so every one counts: a
+    // zero / inf / NaN pivot is detected with one v_cmp_class and only recorded (the factor
+    // is rejected as a whole afterwards, whatever it then contains); each tile lane picks
+    // its own pivot out of w[] once, after the loop.
+    bool bad_any = false;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const double d = lane_bcast(a[j], cb + j);
-      const bool bad = (d == 0.0) || !(fabs(d) <= 1.79e308);
-      const double di = bad ? 0.0 : fast_recip(d);
-      bad_any |= (bad && (cb + j) < nb) ? 1 : 0;
-      if (lane == cb + j) {
-        d_mine = d;
-        di_mine = di;
-      }
+      // classes: sNaN, qNaN, -inf, -0, +0, +inf
+      const bool bad = __builtin_amdgcn_class(d, 0x1 | 0x2 | 0x4 | 0x20 | 0x40 | 0x200);
+      bad_any |= bad && (cb + j) < nb;
+      const double di = fast_recip(d);
       w[j] = a[j];
       const double l = a[j] * di;
 #pragma unroll
@@ -213,12 +213,16 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
     }
     const int tr = lane - cb;  // row inside the tile (tile lanes: 0..15)
     if (tr >= 0 && tr < 16) {
+      double d_mine = 1.0;
 #pragma unroll
-      for (int k = 0; k < 16; ++k)
+      for (int k = 0; k < 16; ++k) {
         if (k < tr) M[lane][cb + k] = a[k];
+        if (k == tr) d_mine = w[k];
+      }
+      const bool ok = !__builtin_amdgcn_class(d_mine, 0x1 | 0x2 | 0x4 | 0x20 | 0x40 | 0x200);
       M[lane][lane] = d_mine;
       dD[lane] = d_mine;
-      dI[lane] = di_mine;
+      dI[lane] = ok ? fast_recip(d_mine) : 0.0;
       if (tr == 0 && bad_any) s_bad = 1;
     } else if (tr >= 16) {  // diagonal-block rows below the tile
 #pragma unroll
