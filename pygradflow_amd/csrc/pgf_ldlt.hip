@@ -1576,16 +1576,8 @@ static void launch_update(DenseLdlt &f, hipStream_t s, const double *Wp, int64_t
     e1 = prof_event(p);
     (void)hipEventRecord(e0, s);
   }
-  // K = 64 (the inner updates between panels): the whole K-depth as ONE staged chunk -- these
-  // launches are a single wave of tiles and latency-bound, so one operand fetch + one barrier
-  // beats four (PGF_UPD_BK64=0 falls back to 16-wide chunks)
-  static const bool bk64 = !(getenv("PGF_UPD_BK64") && atoi(getenv("PGF_UPD_BK64")) == 0);
-  if (KB == 64 && bk64)
-    hipLaunchKernelGGL((k_ldlt_update<64, 64, 64>), dim3(tc, tr), dim3(256), 0, s, f.K, f.ldk, Wp,
-                       ldw, N, nrows, row0, col0, colEnd, kc0, KB | (coh << 20));
-  else
-    hipLaunchKernelGGL((k_ldlt_update<64, 64, 16>), dim3(tc, tr), dim3(256), 0, s, f.K, f.ldk, Wp,
-                       ldw, N, nrows, row0, col0, colEnd, kc0, KB | (coh << 20));
+  hipLaunchKernelGGL((k_ldlt_update<64, 64, 16>), dim3(tc, tr), dim3(256), 0, s, f.K, f.ldk, Wp,
+                     ldw, N, nrows, row0, col0, colEnd, kc0, KB | (coh << 20));
   if (p) {
     (void)hipEventRecord(e1, s);
     p->update_spans.emplace_back(e0, e1);
