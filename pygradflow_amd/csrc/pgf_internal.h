@@ -33,7 +33,9 @@ struct DenseLdlt {
   double *zwork = nullptr;  // solve work vector (Nmax)
   double *Linv = nullptr;   // inverse of every 64 x 64 diagonal block of L, [block][row][64]
   double *LinvT = nullptr;  // the transposes
-  int *flags = nullptr;     // [0] zero-pivot flag, [1] negative pivots
+  int *flags = nullptr;     // [0] zero-pivot flag, [1] negative pivots, [2] solve-chain timeout
+  int *chain = nullptr;     // per 64-block "x ready" epochs of the chained solves: [2][nblk]
+  int chain_epoch = 0;
   int *h_flags = nullptr;   // pinned host mirror
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // look-ahead stream (trailing update)

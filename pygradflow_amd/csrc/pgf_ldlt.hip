@@ -1121,6 +1121,156 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_super(const double *__restrict
   trsv_fwd_body<SUPER>(K, ldk, LinvT, z, x, N, c0);
 }
 
+// ------------------------------------------------------------------ chained triangular solves
+// One launch for a whole triangular solve instead of one per 256-row super-block (20 dependent
+// launches of ~15 us at N = 5120).  One workgroup per 64-row block; block b accumulates the
+// products with the already solved blocks AS THEY BECOME AVAILABLE -- every block publishes
+// its 64 solution entries and then an epoch stamp (release, agent scope), consumers poll the
+// stamp (acquire) -- and finishes with the mat-vec by its inverted diagonal block.  The off-
+// diagonal blocks are final data, so they are fetched before the stamp they wait for.
+//  * Termination: the poll is bounded (a timed-out wait records flags[2] and goes on), every
+//    workgroup walks a finite loop, and a workgroup only waits for blocks with SMALLER
+//    worker index, which are dispatched before it; all workers are resident at once
+//    (N / 64 <= 938 workers of 256 lanes on 256 CUs x 8 slots).
+//  * Placement: workers are the workgroups with id % 8 == 0, i.e. (round-robin dispatch)
+//    all on one XCD, so stamps and solution entries meet in ONE L2; the scopes used are
+//    correct wherever the workgroups land.
+#define CHAIN_SPIN_LIMIT (1 << 22)
+
+__device__ __forceinline__ void chain_wait(const int *stamp, int epoch, int *flags) {
+  for (int it = 0; it < CHAIN_SPIN_LIMIT; ++it) {
+    if (__hip_atomic_load(stamp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == epoch) return;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  atomicOr(&flags[2], 1);
+}
+
+// backward: L^T x = z.  x_b = inv(L_bb)^T (z_b - sum_{a > b} L_ab^T x_a).  In place (x == z) ok.
+__global__ __launch_bounds__(256) void k_trsv_bwd_chain(const double *__restrict__ K, int64_t ldk,
+                                                        const double *__restrict__ Linv,
+                                                        const double *z, double *x, int N,
+                                                        int *__restrict__ stamps, int epoch,
+                                                        int *__restrict__ flags) {
+  if (blockIdx.x & 7) return;
+  __shared__ double part[4][64];
+  __shared__ double rs[64];
+  const int nblk = (N + 63) / 64;
+  const int b = nblk - 1 - (int)(blockIdx.x >> 3);  // last block first
+  const int b0 = b * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // inverse of the diagonal block, rows [16 wave, 16 wave + 16): inv[j][lane]
+  double iv[16];
+  const double *ip = Linv + (size_t)b * 4096 + (size_t)(16 * wave) * 64 + lane;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) iv[t] = ip[t * 64];
+  const double zb = (wave == 0 && b0 + lane < N) ? z[b0 + lane] : 0.0;
+  // column `lane` of L_ab, rows [16 wave, 16 wave + 16), for a = nblk - 1 ... b + 1
+  auto fetch = [&](int a, double (&lv)[16]) {
+    const int r0 = a * 64 + 16 * wave;
+    const double *cp = K + (int64_t)r0 * ldk + b0 + lane;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) lv[t] = (r0 + t < N) ? cp[(int64_t)t * ldk] : 0.0;
+  };
+  double acc = 0.0;
+  double cur[16], nxt[16];
+  int a = nblk - 1;
+  if (a > b) fetch(a, cur);
+  for (; a > b; --a) {
+    if (a - 1 > b) fetch(a - 1, nxt);
+    chain_wait(stamps + a, epoch, flags);
+    const int xr0 = a * 64 + 16 * wave;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const double xv = (xr0 + t < N) ? x[xr0 + t] : 0.0;  // the last block may be short
+      acc = fma(cur[t], xv, acc);
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) cur[t] = nxt[t];
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0) rs[lane] = zb - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+  __syncthreads();
+  // x_i = sum_j inv[j][i] r_j  (j >= i; the stored inverse is zero above the diagonal)
+  double s = 0.0;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) s = fma(iv[t], rs[16 * wave + t], s);
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0) {
+    const double xv = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (b0 + lane < N) x[b0 + lane] = xv;
+    __threadfence();
+    if (lane == 0)
+      __hip_atomic_store(stamps + b, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// forward: L y = z.  y_b = inv(L_bb) (z_b - sum_{a < b} L_ba y_a).  In place ok.
+__global__ __launch_bounds__(256) void k_trsv_fwd_chain(const double *__restrict__ K, int64_t ldk,
+                                                        const double *__restrict__ LinvT,
+                                                        const double *z, double *x, int N,
+                                                        int *__restrict__ stamps, int epoch,
+                                                        int *__restrict__ flags) {
+  if (blockIdx.x & 7) return;
+  __shared__ double part[4][64];
+  __shared__ double rs[64];
+  const int b = (int)(blockIdx.x >> 3);  // first block first
+  const int b0 = b * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // LinvT[j][i] = inv[i][j]: rows j in [16 wave, 16 wave + 16), column i = lane
+  double iv[16];
+  const double *ip = LinvT + (size_t)b * 4096 + (size_t)(16 * wave) * 64 + lane;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) iv[t] = ip[t * 64];
+  const double zb = (wave == 0 && b0 + lane < N) ? z[b0 + lane] : 0.0;
+  // rows [16 wave, 16 wave + 16) of L_ba, column `lane` of block a: lane-partial row sums
+  auto fetch = [&](int a, double (&lv)[16]) {
+    const int r0 = b0 + 16 * wave;
+    const double *cp = K + (int64_t)r0 * ldk + a * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) lv[t] = (r0 + t < N) ? cp[(int64_t)t * ldk] : 0.0;
+  };
+  double acc[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc[t] = 0.0;
+  double cur[16], nxt[16];
+  if (b > 0) fetch(0, cur);
+  for (int a = 0; a < b; ++a) {
+    if (a + 1 < b) fetch(a + 1, nxt);
+    chain_wait(stamps + a, epoch, flags);
+    const double xa = x[a * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = fma(cur[t], xa, acc[t]);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) cur[t] = nxt[t];
+  }
+  // row sums over the 64 lanes (once, after the last block)
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    double v = acc[t];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (lane == 0) rs[16 * wave + t] = v;
+  }
+  __syncthreads();
+  if (wave == 0) rs[lane] = zb - rs[lane];
+  __syncthreads();
+  // y_i = sum_j inv[i][j] r_j
+  double s = 0.0;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) s = fma(iv[t], rs[16 * wave + t], s);
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0) {
+    const double xv = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (b0 + lane < N) x[b0 + lane] = xv;
+    __threadfence();
+    if (lane == 0)
+      __hip_atomic_store(stamps + b, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ------------------------------------------------------------------ batched variants
 // One instance per blockIdx.z (BInst, pgf_internal.h).  Every instance has its own reduced
 // size N = counts[0] + m, known only on the device: the host walks the panel / update
@@ -1526,6 +1676,8 @@ hipError_t ldlt_alloc(DenseLdlt &f, int Nmax, hipStream_t stream) {
   if ((e = hipMalloc(&f.Linv, (rows / 64 + 1) * 4096 * sizeof(double))) != hipSuccess) return e;
   if ((e = hipMalloc(&f.LinvT, (rows / 64 + 1) * 4096 * sizeof(double))) != hipSuccess) return e;
   if ((e = hipMalloc(&f.flags, 4 * sizeof(int))) != hipSuccess) return e;
+  if ((e = hipMalloc(&f.chain, 2 * (rows / 64 + 2) * sizeof(int))) != hipSuccess) return e;
+  if ((e = hipMemset(f.chain, 0, 2 * (rows / 64 + 2) * sizeof(int))) != hipSuccess) return e;
   if ((e = hipHostMalloc(&f.h_flags, 4 * sizeof(int))) != hipSuccess) return e;
   return hipSuccess;
 }
@@ -1539,6 +1691,7 @@ void ldlt_free(DenseLdlt &f) {
   if (f.Linv) (void)hipFree(f.Linv);
   if (f.LinvT) (void)hipFree(f.LinvT);
   if (f.flags) (void)hipFree(f.flags);
+  if (f.chain) (void)hipFree(f.chain);
   if (f.h_flags) (void)hipHostFree(f.h_flags);
   if (f.ev_panel) (void)hipEventDestroy(f.ev_panel);
   if (f.ev_update) (void)hipEventDestroy(f.ev_update);
@@ -1793,10 +1946,23 @@ int ldlt_finish(DenseLdlt &f, hipError_t *err) {
   return f.h_flags[0] ? 1 : 0;
 }
 
+// PGF_TRSV_CHAIN=0: one launch per 256-row super-block (the earlier scheme) instead of the
+// chained single-launch solves
+static bool use_chain() {
+  static const bool on = !(getenv("PGF_TRSV_CHAIN") && atoi(getenv("PGF_TRSV_CHAIN")) == 0);
+  return on;
+}
+
 hipError_t ldlt_backsolve_async(DenseLdlt &f, const double *w, double *sol) {
   const int N = f.N;
   hipStream_t s = f.stream;
   if (N == 0) return hipSuccess;
+  if (use_chain()) {
+    const int nblk = (N + 63) / 64;
+    hipLaunchKernelGGL(k_trsv_bwd_chain, dim3(8 * nblk), dim3(256), 0, s, f.K, f.ldk, f.Linv, w, sol,
+                       N, f.chain, ++f.chain_epoch, f.flags);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(k_vec_copy_strided, dim3((N + 255) / 256), dim3(256), 0, s, f.zwork, w, N);
   constexpr int SUPER = 256;
   const int last = ((N - 1) / SUPER) * SUPER;
@@ -1812,13 +1978,19 @@ hipError_t ldlt_solve_async(DenseLdlt &f, const double *rhs, double *sol) {
   const int N = f.N;
   hipStream_t s = f.stream;
   if (N == 0) return hipSuccess;
-  // forward: L y = rhs  (work in zwork, y lands in sol)
-  hipLaunchKernelGGL(k_vec_copy_strided, dim3((N + 255) / 256), dim3(256), 0, s, f.zwork, rhs, N);
-  for (int c0 = 0; c0 < N; c0 += 256) {
-    const int below = N - (c0 + 256);
-    const int g = below > 0 ? (below + 63) / 64 : 1;
-    hipLaunchKernelGGL(k_trsv_fwd_super<256>, dim3(g), dim3(256), 0, s, f.K, f.ldk, f.LinvT,
-                       f.zwork, sol, N, c0);
+  // forward: L y = rhs  (y lands in sol)
+  if (use_chain()) {
+    const int nblk = (N + 63) / 64;
+    hipLaunchKernelGGL(k_trsv_fwd_chain, dim3(8 * nblk), dim3(256), 0, s, f.K, f.ldk, f.LinvT, rhs,
+                       sol, N, f.chain + (f.Nmax + 64) / 64 + 2, ++f.chain_epoch, f.flags);
+  } else {
+    hipLaunchKernelGGL(k_vec_copy_strided, dim3((N + 255) / 256), dim3(256), 0, s, f.zwork, rhs, N);
+    for (int c0 = 0; c0 < N; c0 += 256) {
+      const int below = N - (c0 + 256);
+      const int g = below > 0 ? (below + 63) / 64 : 1;
+      hipLaunchKernelGGL(k_trsv_fwd_super<256>, dim3(g), dim3(256), 0, s, f.K, f.ldk, f.LinvT,
+                         f.zwork, sol, N, c0);
+    }
   }
   // diagonal: y <- D^-1 y
   hipLaunchKernelGGL(k_vec_scale, dim3((N + 255) / 256), dim3(256), 0, s, sol, f.dinv, N);
