@@ -1138,11 +1138,18 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_super(const double *__restrict
 #define CHAIN_SPIN_LIMIT (1 << 22)
 
 __device__ __forceinline__ void chain_wait(const int *stamp, int epoch, int *flags) {
+  // relaxed polls (an acquire per poll invalidates the caches every time round: 20 us per
+  // hand-over), ONE acquire fence once the stamp is there
+  bool seen = false;
   for (int it = 0; it < CHAIN_SPIN_LIMIT; ++it) {
-    if (__hip_atomic_load(stamp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == epoch) return;
+    if (__hip_atomic_load(stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) {
+      seen = true;
+      break;
+    }
     __builtin_amdgcn_s_sleep(1);
   }
-  atomicOr(&flags[2], 1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (!seen) atomicOr(&flags[2], 1);
 }
 
 // backward: L^T x = z.  x_b = inv(L_bb)^T (z_b - sum_{a > b} L_ab^T x_a).  In place (x == z) ok.
