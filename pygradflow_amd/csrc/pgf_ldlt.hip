@@ -1148,7 +1148,9 @@ __device__ __forceinline__ void chain_wait(const int *stamp, int epoch, int *fla
     }
     __builtin_amdgcn_s_sleep(1);
   }
+#ifndef PGF_CHAIN_LIGHT
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
   if (!seen) atomicOr(&flags[2], 1);
 }
 
@@ -1188,7 +1190,13 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_chain(const double *__restrict
     const int xr0 = a * 64 + 16 * wave;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
+#ifdef PGF_CHAIN_LIGHT
+      const double xv = (xr0 + t < N) ? __hip_atomic_load(x + xr0 + t, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT)
+                                      : 0.0;
+#else
       const double xv = (xr0 + t < N) ? x[xr0 + t] : 0.0;  // the last block may be short
+#endif
       acc = fma(cur[t], xv, acc);
     }
 #pragma unroll
@@ -1206,10 +1214,18 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_chain(const double *__restrict
   __syncthreads();
   if (wave == 0) {
     const double xv = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+#ifdef PGF_CHAIN_LIGHT
+    if (b0 + lane < N)
+      __hip_atomic_store(x + b0 + lane, xv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0)
+      __hip_atomic_store(stamps + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
     if (b0 + lane < N) x[b0 + lane] = xv;
     __threadfence();
     if (lane == 0)
       __hip_atomic_store(stamps + b, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
   }
 }
 
@@ -1246,7 +1262,11 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_chain(const double *__restrict
   for (int a = 0; a < b; ++a) {
     if (a + 1 < b) fetch(a + 1, nxt);
     chain_wait(stamps + a, epoch, flags);
+#ifdef PGF_CHAIN_LIGHT
+    const double xa = __hip_atomic_load(x + a * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
     const double xa = x[a * 64 + lane];
+#endif
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[t] = fma(cur[t], xa, acc[t]);
 #pragma unroll
@@ -1271,10 +1291,18 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_chain(const double *__restrict
   __syncthreads();
   if (wave == 0) {
     const double xv = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+#ifdef PGF_CHAIN_LIGHT
+    if (b0 + lane < N)
+      __hip_atomic_store(x + b0 + lane, xv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0)
+      __hip_atomic_store(stamps + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
     if (b0 + lane < N) x[b0 + lane] = xv;
     __threadfence();
     if (lane == 0)
       __hip_atomic_store(stamps + b, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
   }
 }
 
