@@ -17,8 +17,7 @@ ARCH = "gfx950"
 SOURCES = [
     ("pgf_kernels.hip", ["-ffp-contract=off"]),
     ("pgf_sparse.hip", ["-ffp-contract=off"]),
-    ("pgf_ldlt.hip", (["-DPGF_RECIP_ONE_STEP"] if os.environ.get("PGF_BUILD_RECIP1") else [])
-     + (["-DPGF_CHAIN_LIGHT"] if os.environ.get("PGF_BUILD_CHAIN_LIGHT") else [])),
+    ("pgf_ldlt.hip", ["-DPGF_RECIP_ONE_STEP"] if os.environ.get("PGF_BUILD_RECIP1") else []),
     ("pgf_api.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]

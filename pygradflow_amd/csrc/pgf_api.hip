@@ -56,6 +56,8 @@ struct pgf_linsolver {
 };
 
 static const char *k_no_handle = "null handle";
+static const char *k_chain_msg = "chained triangular solve failed its placement / timeout check; "
+                                 "it is switched off now, repeat the call";
 
 static int fail(pgf_handle h, int code, const char *msg) {
   if (h) h->err = msg;
@@ -154,6 +156,7 @@ int pgf_create(int n, int m, int device, unsigned flags, pgf_handle *out) {
       pgf_destroy(h);
       return PGF_HIP_ERROR + (int)e;
     }
+    for (int i = 0; i < 4; ++i) h->fac.h_flags[i] = 0;
   } else if ((e = ldlt_alloc(h->fac, N, h->stream)) != hipSuccess) {
     pgf_destroy(h);
     return PGF_HIP_ERROR + (int)e;
@@ -400,6 +403,7 @@ static int factor_finish(pgf_handle h) {
   const int st = ldlt_finish(h->fac, &e);
   if (st < 0) return hip_fail(h, e, "factor");
   if (st == 1) return fail(h, PGF_SINGULAR, "zero or non-finite pivot in LDL^T of the KKT matrix");
+  if (st == 2) return fail(h, PGF_HIP_ERROR, k_chain_msg);
   return PGF_OK;
 }
 
@@ -510,6 +514,7 @@ int pgf_newton_solve(pgf_handle h, const double *x, const double *y, const doubl
   if (yn && (rc = down(h, yn, h->yn, h->m * sizeof(double)))) return rc;
   if ((rc = down(h, h->h_scal, h->scal, sizeof(double)))) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (!h->sparse && ldlt_chain_check(h->fac)) return fail(h, PGF_HIP_ERROR, k_chain_msg);
   if (diff) *diff = h->h_scal[0];
   return PGF_OK;
 }
@@ -556,6 +561,7 @@ int pgf_linear_solve(pgf_handle h, const double *rhs, int trans, double *sol) {
   HIPCHK(h, ldlt_solve_async(h->fac, h->rhs, h->sol));
   if ((rc = down(h, sol, h->sol, h->N * sizeof(double)))) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (ldlt_chain_check(h->fac)) return fail(h, PGF_HIP_ERROR, k_chain_msg);
   return PGF_OK;
 }
 
@@ -845,6 +851,7 @@ int pgf_qp_sync(pgf_handle h, int *n_neg, double *diff) {
   const int st = ldlt_finish(h->fac, &e);  // flags are only rewritten by a factor launch
   if (st < 0) return hip_fail(h, e, "step");
   if (st == 1) return fail(h, PGF_SINGULAR, "zero or non-finite pivot in LDL^T of the KKT matrix");
+  if (st == 2) return fail(h, PGF_HIP_ERROR, k_chain_msg);
   if (n_neg) *n_neg = h->fac.n_neg;
   if (diff) *diff = h->h_scal[0];
   return PGF_OK;
@@ -1373,6 +1380,7 @@ int pgf_ls_solve(pgf_ls_handle ls, const double *rhs, int trans, double *sol) {
   if (e == hipSuccess)
     e = hipMemcpyAsync(sol, ls->sol, ls->N * sizeof(double), hipMemcpyDeviceToHost, ls->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ls->stream);
+  if (e == hipSuccess && ldlt_chain_check(ls->fac)) return PGF_HIP_ERROR;
   return e == hipSuccess ? PGF_OK : PGF_HIP_ERROR + (int)e;
 }
 

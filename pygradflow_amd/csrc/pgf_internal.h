@@ -33,10 +33,11 @@ struct DenseLdlt {
   double *zwork = nullptr;  // solve work vector (Nmax)
   double *Linv = nullptr;   // inverse of every 64 x 64 diagonal block of L, [block][row][64]
   double *LinvT = nullptr;  // the transposes
-  int *flags = nullptr;     // [0] zero-pivot flag, [1] negative pivots, [2] solve-chain timeout
-  int *chain = nullptr;     // per 64-block "x ready" epochs of the chained solves: [2][nblk]
-  int chain_epoch = 0;
-  int *h_flags = nullptr;   // pinned host mirror
+  int *flags = nullptr;     // [0] zero-pivot flag, [1] negative pivots
+  // chained solves: [0, S) backward stamps, [S, 2S) forward stamps, [2S] XCC slot, [2S+1] bad
+  int *chain = nullptr;
+  int chain_stride = 0, chain_epoch = 0;
+  int *h_flags = nullptr;   // pinned host mirror ([3]: status word of the chained solves)
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // look-ahead stream (trailing update)
   hipEvent_t ev_panel = nullptr, ev_update = nullptr;
@@ -53,12 +54,15 @@ hipError_t ldlt_alloc(DenseLdlt &f, int Nmax, hipStream_t stream);
 void ldlt_free(DenseLdlt &f);
 // enqueue the factorisation of the leading N x N lower triangle (+ rows up to nrows)
 hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows);
-// wait and read flags: returns 0 ok / 1 singular; sets f.n_neg
+// wait and read flags: returns 0 ok / 1 singular / 2 a chained solve failed its own checks;
+// sets f.n_neg
 int ldlt_finish(DenseLdlt &f, hipError_t *err);
 // sol <- K^{-1} rhs on device vectors of length N (rhs preserved if rhs != sol)
 hipError_t ldlt_solve_async(DenseLdlt &f, const double *rhs, double *sol);
 // backward half only: sol <- L^{-T} w, w already equals D^{-1} L^{-1} rhs (row N trick)
 hipError_t ldlt_backsolve_async(DenseLdlt &f, const double *w, double *sol);
+// after a host sync: nonzero if a chained solve reported a timeout / placement problem
+int ldlt_chain_check(DenseLdlt &f);
 
 // ---- batched mode ----------------------------------------------------------
 // One entry per instance of a batch (all instances share n, m): the device addresses of an

@@ -1125,33 +1125,37 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_super(const double *__restrict
 // One launch for a whole triangular solve instead of one per 256-row super-block (20 dependent
 // launches of ~15 us at N = 5120).  One workgroup per 64-row block; block b accumulates the
 // products with the already solved blocks AS THEY BECOME AVAILABLE -- every block publishes
-// its 64 solution entries and then an epoch stamp (release, agent scope), consumers poll the
-// stamp (acquire) -- and finishes with the mat-vec by its inverted diagonal block.  The off-
-// diagonal blocks are final data, so they are fetched before the stamp they wait for.
-//  * Termination: the poll is bounded (a timed-out wait records flags[2] and goes on), every
-//    workgroup walks a finite loop, and a workgroup only waits for blocks with SMALLER
-//    worker index, which are dispatched before it; all workers are resident at once
-//    (N / 64 <= 938 workers of 256 lanes on 256 CUs x 8 slots).
-//  * Placement: workers are the workgroups with id % 8 == 0, i.e. (round-robin dispatch)
-//    all on one XCD, so stamps and solution entries meet in ONE L2; the scopes used are
-//    correct wherever the workgroups land.
+// its 64 solution entries and then an epoch stamp, consumers poll the stamp -- and finishes
+// with the mat-vec by its inverted diagonal block.  The off-diagonal blocks are final data, so
+// they are fetched before the stamp they wait for.
+//  * Hand-over protocol: the workers are the workgroups with id % 8 == 0, which the
+//    round-robin dispatch puts on ONE XCD; solution entries and stamps are written and read
+//    with L1-bypassing (agent-scope relaxed atomic) accesses and therefore meet in that XCD's
+//    L2 -- no L2 write-back / invalidate per hand-over (with agent-scope release / acquire
+//    fences a hand-over costs 11 us instead of 2.5 us and the chain is slower than the
+//    launches it replaces).  The placement is CHECKED, not assumed: every worker reads its
+//    XCC id (s_getreg HW_REG_XCC_ID) and compares it with the other workers' through one
+//    atomicMax; a mismatch or a timed-out wait sets ctl[1], which the host reads at the next
+//    synchronisation: the call fails loudly and the chained solves are switched off.
+//  * Termination: polls are bounded, every workgroup walks a finite loop, and a workgroup only
+//    waits for workers with a SMALLER index, which are dispatched before it.
 #define CHAIN_SPIN_LIMIT (1 << 22)
 
-__device__ __forceinline__ void chain_wait(const int *stamp, int epoch, int *flags) {
-  // relaxed polls (an acquire per poll invalidates the caches every time round: 20 us per
-  // hand-over), ONE acquire fence once the stamp is there
-  bool seen = false;
+__device__ __forceinline__ void chain_wait(const int *stamp, int epoch, int *ctl) {
   for (int it = 0; it < CHAIN_SPIN_LIMIT; ++it) {
-    if (__hip_atomic_load(stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) {
-      seen = true;
-      break;
-    }
+    if (__hip_atomic_load(stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return;
     __builtin_amdgcn_s_sleep(1);
   }
-#ifndef PGF_CHAIN_LIGHT
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
-  if (!seen) atomicOr(&flags[2], 1);
+  atomicOr(&ctl[1], 1);
+}
+
+// all workers of a launch must sit on one XCD: ctl[0] = max over workers of (epoch << 4 | xcc)
+__device__ __forceinline__ void chain_check_xcc(int epoch, int *ctl) {
+  if (threadIdx.x == 0) {
+    const int mine = (epoch << 4) | (int)(__builtin_amdgcn_s_getreg(6164) & 15);  // XCC_ID[3:0]
+    const int old = atomicMax(&ctl[0], mine);
+    if ((old >> 4) == epoch && old != mine) atomicOr(&ctl[1], 2);
+  }
 }
 
 // backward: L^T x = z.  x_b = inv(L_bb)^T (z_b - sum_{a > b} L_ab^T x_a).  In place (x == z) ok.
@@ -1159,8 +1163,9 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_chain(const double *__restrict
                                                         const double *__restrict__ Linv,
                                                         const double *z, double *x, int N,
                                                         int *__restrict__ stamps, int epoch,
-                                                        int *__restrict__ flags) {
+                                                        int *__restrict__ ctl) {
   if (blockIdx.x & 7) return;
+  chain_check_xcc(epoch, ctl);
   __shared__ double part[4][64];
   __shared__ double rs[64];
   const int nblk = (N + 63) / 64;
@@ -1186,17 +1191,13 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_chain(const double *__restrict
   if (a > b) fetch(a, cur);
   for (; a > b; --a) {
     if (a - 1 > b) fetch(a - 1, nxt);
-    chain_wait(stamps + a, epoch, flags);
+    chain_wait(stamps + a, epoch, ctl);
     const int xr0 = a * 64 + 16 * wave;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-#ifdef PGF_CHAIN_LIGHT
       const double xv = (xr0 + t < N) ? __hip_atomic_load(x + xr0 + t, __ATOMIC_RELAXED,
                                                           __HIP_MEMORY_SCOPE_AGENT)
                                       : 0.0;
-#else
-      const double xv = (xr0 + t < N) ? x[xr0 + t] : 0.0;  // the last block may be short
-#endif
       acc = fma(cur[t], xv, acc);
     }
 #pragma unroll
@@ -1214,18 +1215,11 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_chain(const double *__restrict
   __syncthreads();
   if (wave == 0) {
     const double xv = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-#ifdef PGF_CHAIN_LIGHT
     if (b0 + lane < N)
       __hip_atomic_store(x + b0 + lane, xv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0)
       __hip_atomic_store(stamps + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    if (b0 + lane < N) x[b0 + lane] = xv;
-    __threadfence();
-    if (lane == 0)
-      __hip_atomic_store(stamps + b, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-#endif
   }
 }
 
@@ -1234,8 +1228,9 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_chain(const double *__restrict
                                                         const double *__restrict__ LinvT,
                                                         const double *z, double *x, int N,
                                                         int *__restrict__ stamps, int epoch,
-                                                        int *__restrict__ flags) {
+                                                        int *__restrict__ ctl) {
   if (blockIdx.x & 7) return;
+  chain_check_xcc(epoch, ctl);
   __shared__ double part[4][64];
   __shared__ double rs[64];
   const int b = (int)(blockIdx.x >> 3);  // first block first
@@ -1261,12 +1256,8 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_chain(const double *__restrict
   if (b > 0) fetch(0, cur);
   for (int a = 0; a < b; ++a) {
     if (a + 1 < b) fetch(a + 1, nxt);
-    chain_wait(stamps + a, epoch, flags);
-#ifdef PGF_CHAIN_LIGHT
+    chain_wait(stamps + a, epoch, ctl);
     const double xa = __hip_atomic_load(x + a * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    const double xa = x[a * 64 + lane];
-#endif
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[t] = fma(cur[t], xa, acc[t]);
 #pragma unroll
@@ -1291,18 +1282,11 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_chain(const double *__restrict
   __syncthreads();
   if (wave == 0) {
     const double xv = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-#ifdef PGF_CHAIN_LIGHT
     if (b0 + lane < N)
       __hip_atomic_store(x + b0 + lane, xv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0)
       __hip_atomic_store(stamps + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    if (b0 + lane < N) x[b0 + lane] = xv;
-    __threadfence();
-    if (lane == 0)
-      __hip_atomic_store(stamps + b, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-#endif
   }
 }
 
@@ -1711,9 +1695,11 @@ hipError_t ldlt_alloc(DenseLdlt &f, int Nmax, hipStream_t stream) {
   if ((e = hipMalloc(&f.Linv, (rows / 64 + 1) * 4096 * sizeof(double))) != hipSuccess) return e;
   if ((e = hipMalloc(&f.LinvT, (rows / 64 + 1) * 4096 * sizeof(double))) != hipSuccess) return e;
   if ((e = hipMalloc(&f.flags, 4 * sizeof(int))) != hipSuccess) return e;
-  if ((e = hipMalloc(&f.chain, 2 * (rows / 64 + 2) * sizeof(int))) != hipSuccess) return e;
-  if ((e = hipMemset(f.chain, 0, 2 * (rows / 64 + 2) * sizeof(int))) != hipSuccess) return e;
+  f.chain_stride = (int)(rows / 64 + 2);
+  if ((e = hipMalloc(&f.chain, (2 * f.chain_stride + 4) * sizeof(int))) != hipSuccess) return e;
+  if ((e = hipMemset(f.chain, 0, (2 * f.chain_stride + 4) * sizeof(int))) != hipSuccess) return e;
   if ((e = hipHostMalloc(&f.h_flags, 4 * sizeof(int))) != hipSuccess) return e;
+  for (int i = 0; i < 4; ++i) f.h_flags[i] = 0;
   return hipSuccess;
 }
 
@@ -1978,14 +1964,34 @@ int ldlt_finish(DenseLdlt &f, hipError_t *err) {
   if (e != hipSuccess) return -1;
   f.n_neg = f.h_flags[1];
   f.factored = (f.h_flags[0] == 0);
-  return f.h_flags[0] ? 1 : 0;
+  if (f.h_flags[0]) return 1;
+  return ldlt_chain_check(f) ? 2 : 0;
 }
 
 // PGF_TRSV_CHAIN=0: one launch per 256-row super-block (the earlier scheme) instead of the
-// chained single-launch solves
+// chained single-launch solves; also switched off for the rest of the process when a chained
+// solve reports a placement / timeout problem (ldlt_chain_check)
+static bool g_chain_off = false;
 static bool use_chain() {
   static const bool on = !(getenv("PGF_TRSV_CHAIN") && atoi(getenv("PGF_TRSV_CHAIN")) == 0);
-  return on;
+  return on && !g_chain_off;
+}
+
+// after a host synchronisation of f.stream: did a chained solve since the last check fail its
+// own checks?  (bit 0: a wait timed out, bit 1: workers on different XCDs)
+int ldlt_chain_check(DenseLdlt &f) {
+  if (!f.chain || !f.h_flags) return 0;  // banded handles have no dense factor
+  const int bad = f.h_flags[3];
+  if (!bad) return 0;
+  f.h_flags[3] = 0;
+  g_chain_off = true;
+  (void)hipMemsetAsync(f.chain + 2 * f.chain_stride + 1, 0, sizeof(int), f.stream);
+  return bad;
+}
+
+static hipError_t chain_report(DenseLdlt &f) {
+  return hipMemcpyAsync(f.h_flags + 3, f.chain + 2 * f.chain_stride + 1, sizeof(int),
+                        hipMemcpyDeviceToHost, f.stream);
 }
 
 hipError_t ldlt_backsolve_async(DenseLdlt &f, const double *w, double *sol) {
@@ -1995,8 +2001,8 @@ hipError_t ldlt_backsolve_async(DenseLdlt &f, const double *w, double *sol) {
   if (use_chain()) {
     const int nblk = (N + 63) / 64;
     hipLaunchKernelGGL(k_trsv_bwd_chain, dim3(8 * nblk), dim3(256), 0, s, f.K, f.ldk, f.Linv, w, sol,
-                       N, f.chain, ++f.chain_epoch, f.flags);
-    return hipGetLastError();
+                       N, f.chain, ++f.chain_epoch, f.chain + 2 * f.chain_stride);
+    return chain_report(f);
   }
   hipLaunchKernelGGL(k_vec_copy_strided, dim3((N + 255) / 256), dim3(256), 0, s, f.zwork, w, N);
   constexpr int SUPER = 256;
@@ -2017,7 +2023,8 @@ hipError_t ldlt_solve_async(DenseLdlt &f, const double *rhs, double *sol) {
   if (use_chain()) {
     const int nblk = (N + 63) / 64;
     hipLaunchKernelGGL(k_trsv_fwd_chain, dim3(8 * nblk), dim3(256), 0, s, f.K, f.ldk, f.LinvT, rhs,
-                       sol, N, f.chain + (f.Nmax + 64) / 64 + 2, ++f.chain_epoch, f.flags);
+                       sol, N, f.chain + f.chain_stride, ++f.chain_epoch,
+                       f.chain + 2 * f.chain_stride);
   } else {
     hipLaunchKernelGGL(k_vec_copy_strided, dim3((N + 255) / 256), dim3(256), 0, s, f.zwork, rhs, N);
     for (int c0 = 0; c0 < N; c0 += 256) {
