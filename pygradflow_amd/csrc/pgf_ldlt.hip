@@ -1152,9 +1152,12 @@ __device__ __forceinline__ void chain_wait(const int *stamp, int epoch, int *ctl
 // all workers of a launch must sit on one XCD: ctl[0] = max over workers of (epoch << 4 | xcc)
 __device__ __forceinline__ void chain_check_xcc(int epoch, int *ctl) {
   if (threadIdx.x == 0) {
-    const int mine = (epoch << 4) | (int)(__builtin_amdgcn_s_getreg(6164) & 15);  // XCC_ID[3:0]
+    // 27 bits of epoch: after 2^27 solves the slot stops changing and the check goes quiet
+    // (no false alarms); the stamps themselves compare full 32-bit epochs
+    const int ep = epoch & 0x7ffffff;
+    const int mine = (ep << 4) | (int)(__builtin_amdgcn_s_getreg(6164) & 15);  // XCC_ID[3:0]
     const int old = atomicMax(&ctl[0], mine);
-    if ((old >> 4) == epoch && old != mine) atomicOr(&ctl[1], 2);
+    if ((old >> 4) == ep && old != mine) atomicOr(&ctl[1], 2);
   }
 }
 
