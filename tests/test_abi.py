@@ -52,3 +52,55 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(root, f)).read()
                 assert "oracle" not in src.replace("no CPU fallback", ""), f
+
+
+def test_single_precision_is_refused_before_touching_the_gpu():
+    """Precision.Single is outside the 1e-10 contract: the step solver must say
+    so instead of computing in the wrong precision."""
+    import numpy as np
+    import pytest
+
+    from pygradflow_amd import problems
+    from pygradflow_amd.iterate import Iterate
+    from pygradflow_amd.params import Params
+    from pygradflow_amd.step_solver import HipStepSolver
+
+    prob = problems.dense_qp(8, 2, seed=0)
+    par = Params(precision="Single")
+    it = Iterate(prob, par, np.zeros(8, dtype=np.float32), np.zeros(2, dtype=np.float32))
+    with pytest.raises(ValueError, match="float64 only"):
+        HipStepSolver(prob, par, it, 1.0, 1.0)
+    with pytest.raises(ValueError, match="positive"):
+        HipStepSolver(prob, Params(), it, -1.0, 1.0)
+
+
+def test_shard_ranges_cover_every_instance_once():
+    from pygradflow_amd.batched import shard_range
+
+    for B in (0, 1, 7, 256, 257):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                lo, hi = shard_range(B, world, r)
+                assert 0 <= lo <= hi <= B
+                seen.extend(range(lo, hi))
+            assert seen == list(range(B))
+
+
+def test_unsupported_step_solver_formulations_say_so():
+    """Standard / Extended / Asymmetric are alternative routes to the same Newton step; asking
+    the factory for them without a plugin must not silently run something else."""
+    import numpy as np
+    import pytest
+
+    from pygradflow_amd import problems
+    from pygradflow_amd.iterate import Iterate
+    from pygradflow_amd.newton import make_step_solver
+    from pygradflow_amd.params import Params
+
+    prob = problems.dense_qp(8, 2, seed=0)
+    for kind in ("Standard", "Extended", "Asymmetric"):
+        par = Params(step_solver_type=kind)
+        it = Iterate(prob, par, np.zeros(8), np.zeros(2))
+        with pytest.raises(NotImplementedError, match=kind):
+            make_step_solver(prob, par, it, 1.0, 1.0)
