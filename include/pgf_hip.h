@@ -79,6 +79,13 @@ int pgf_set_outer(pgf_handle h, const double *xhat, const double *yhat, double d
  * Invalidates K and its factor. */
 int pgf_set_derivs_dense(pgf_handle h, const double *H, int64_t ldh, const double *J,
                          int64_t ldj, int loc);
+/* The same matrices as scipy CSR (what Iterate.aug_lag_deriv_xx / _xy return,
+ * iterate.py:99-110): host arrays, int32 indices, duplicates are summed.  Only the
+ * non-zeros cross PCIe; the dense H, J the factorisation reads are rebuilt on the device.
+ * For problems whose derivatives are sparse but not banded (the banded path has its own
+ * entry points below). */
+int pgf_set_derivs_csr(pgf_handle h, const int *Hptr, const int *Hidx, const double *Hval,
+                       const int *Jptr, const int *Jidx, const double *Jval);
 
 /* StepFunc.compute_active_set (implicit_func.py:72-74) =
  * projection_initial (:233-246, tau = NaN means None) + compute_active_set_box (:21-44).

@@ -40,6 +40,7 @@ SIGNATURES = {
     "pgf_set_bounds": (C.c_int, [_h, _dp, _dp]),
     "pgf_set_outer": (C.c_int, [_h, _dp, _dp, C.c_double, C.c_double]),
     "pgf_set_derivs_dense": (C.c_int, [_h, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int]),
+    "pgf_set_derivs_csr": (C.c_int, [_h, _ip, _ip, _dp, _ip, _ip, _dp]),
     "pgf_active_set": (C.c_int, [_h, _dp, _dp, C.c_double, _u8p]),
     "pgf_set_active_set": (C.c_int, [_h, _u8p]),
     "pgf_factor": (C.c_int, [_h, _ip]),

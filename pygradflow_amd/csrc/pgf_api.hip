@@ -27,6 +27,10 @@ struct pgf_solver {
   int64_t ldh = 0, ldj = 0;
   bool ownH = false, ownJ = false;
   double *Hown = nullptr, *Jown = nullptr;  // library-owned storage (reused across uploads)
+  // staging of pgf_set_derivs_csr (grown on demand): row pointers, column indices, values
+  int *csr_ptr = nullptr, *csr_idx = nullptr;
+  double *csr_val = nullptr;
+  size_t csr_ptr_cap = 0, csr_nnz_cap = 0;
   double *lb = nullptr, *ub = nullptr, *slb = nullptr, *sub = nullptr;
   double *xhat = nullptr, *yhat = nullptr;
   double *x = nullptr, *y = nullptr, *xn = nullptr, *yn = nullptr;
@@ -170,7 +174,7 @@ int pgf_destroy(pgf_handle h) {
   if (!h) return PGF_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void *ptrs[] = {h->Hown, h->Jown, h->lb,  h->ub,   h->slb,  h->sub,      h->xhat, h->yhat,
+  void *ptrs[] = {h->csr_ptr, h->csr_idx, h->csr_val, h->Hown, h->Jown, h->lb,  h->ub,   h->slb,  h->sub,      h->xhat, h->yhat,
                   h->x,    h->y,    h->xn,  h->yn,   h->g,    h->c,        h->F,    h->b0full,
                   h->rhs,  h->sol,  h->dx,  h->dy,   h->q,    h->b,        h->w,    h->tmpn,
                   h->partial, h->red, h->scal, h->mask, h->mask_new, h->idxI, h->idxA, h->pos,
@@ -284,6 +288,73 @@ int pgf_set_derivs_dense(pgf_handle h, const double *H, int64_t ldh, const doubl
   int rc;
   if ((rc = set_matrix(h, H, ldh, h->n, h->n, loc, &h->Hown, &h->H, &h->ldh, &h->ownH))) return rc;
   if ((rc = set_matrix(h, J, ldj, h->m, h->n, loc, &h->Jown, &h->J, &h->ldj, &h->ownJ))) return rc;
+  h->derivs_set = true;
+  invalidate_factor(h);
+  return PGF_OK;
+}
+
+// one CSR matrix (host arrays) -> the library-owned dense buffer *own (rows x cols)
+static int csr_matrix_to_dense(pgf_handle h, int rows, int cols, const int *ptr, const int *idx,
+                               const double *val, double **own, double **cur, int64_t *curld,
+                               bool *owned) {
+  if (rows == 0 || cols == 0) {
+    *cur = nullptr;
+    *curld = cols;
+    return PGF_OK;
+  }
+  if (!ptr) return fail(h, PGF_INVALID, "null CSR row pointer");
+  const int nnz = ptr[rows];
+  if (ptr[0] != 0 || nnz < 0 || (nnz && (!idx || !val)))
+    return fail(h, PGF_INVALID, "bad CSR arrays");
+  for (int r = 0; r < rows; ++r)
+    if (ptr[r + 1] < ptr[r]) return fail(h, PGF_INVALID, "CSR row pointers must be non-decreasing");
+  for (int p = 0; p < nnz; ++p)
+    if (idx[p] < 0 || idx[p] >= cols) return fail(h, PGF_INVALID, "CSR column index out of range");
+  if ((size_t)rows + 1 > h->csr_ptr_cap) {
+    if (h->csr_ptr) (void)hipFree(h->csr_ptr);
+    h->csr_ptr = nullptr;
+    HIPCHK(h, dalloc(&h->csr_ptr, (size_t)rows + 1));
+    h->csr_ptr_cap = (size_t)rows + 1;
+  }
+  if ((size_t)nnz > h->csr_nnz_cap) {
+    if (h->csr_idx) (void)hipFree(h->csr_idx);
+    if (h->csr_val) (void)hipFree(h->csr_val);
+    h->csr_idx = nullptr;
+    h->csr_val = nullptr;
+    const size_t cap = (size_t)nnz + (size_t)nnz / 4 + 16;
+    HIPCHK(h, dalloc(&h->csr_idx, cap));
+    HIPCHK(h, dalloc(&h->csr_val, cap));
+    h->csr_nnz_cap = cap;
+  }
+  if (!*own) HIPCHK(h, dalloc(own, (size_t)rows * cols));
+  int rc;
+  if ((rc = up(h, h->csr_ptr, ptr, ((size_t)rows + 1) * sizeof(int)))) return rc;
+  if (nnz) {
+    if ((rc = up(h, h->csr_idx, idx, (size_t)nnz * sizeof(int)))) return rc;
+    if ((rc = up(h, h->csr_val, val, (size_t)nnz * sizeof(double)))) return rc;
+  }
+  HIPCHK(h, hipMemsetAsync(*own, 0, (size_t)rows * cols * sizeof(double), h->stream));
+  launch_csr_to_dense(h->stream, rows, h->csr_ptr, h->csr_idx, h->csr_val, *own, cols);
+  // the staging arrays are reused by the next matrix: finish before returning
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  *cur = *own;
+  *curld = cols;
+  *owned = true;
+  return PGF_OK;
+}
+
+int pgf_set_derivs_csr(pgf_handle h, const int *Hptr, const int *Hidx, const double *Hval,
+                       const int *Jptr, const int *Jidx, const double *Jval) {
+  if (!h) return PGF_INVALID;
+  if (h->sparse) return fail(h, PGF_INVALID, "banded handles take pgf_sparse_set_pattern / _values");
+  (void)hipSetDevice(h->device);
+  int rc;
+  if ((rc = csr_matrix_to_dense(h, h->n, h->n, Hptr, Hidx, Hval, &h->Hown, &h->H, &h->ldh,
+                                &h->ownH)))
+    return rc;
+  if ((rc = csr_matrix_to_dense(h, h->m, h->n, Jptr, Jidx, Jval, &h->Jown, &h->J, &h->ldj,
+                                &h->ownJ)))
+    return rc;
   h->derivs_set = true;
   invalidate_factor(h);
   return PGF_OK;

@@ -44,3 +44,5 @@ void launch_final_reduce(hipStream_t s, const double *red, int cnt, double *out,
 void launch_measures(hipStream_t s, int n, int m, double active_tol, const double *x,
                      const double *y, const double *r, const double *c, const double *lb,
                      const double *ub, double *red, double *out);
+void launch_csr_to_dense(hipStream_t s, int rows, const int *ptr, const int *idx, const double *val,
+                         double *dst, int64_t ld);

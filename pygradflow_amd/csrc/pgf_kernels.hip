@@ -692,6 +692,29 @@ void launch_measures(hipStream_t s, int n, int m, double active_tol, const doubl
   hipLaunchKernelGGL(k_measures_final, dim3(1), dim3(256), 0, s, red, nb, out);
 }
 
+// ---------------------------------------------------------------- CSR -> dense (plugin path)
+// dst (rows x ld, zeroed beforehand) += CSR entries; one wavefront per row.  Duplicate entries
+// of a row are summed in storage order by lane 0 ... in practice scipy's canonical CSR has
+// none, and a plain store per entry would drop them silently, so entries are accumulated.
+__global__ __launch_bounds__(256) void k_csr_to_dense(int rows, const int *__restrict__ ptr,
+                                                      const int *__restrict__ idx,
+                                                      const double *__restrict__ val,
+                                                      double *__restrict__ dst, int64_t ld) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int p0 = ptr[r], p1 = ptr[r + 1];
+  double *row = dst + (int64_t)r * ld;
+  for (int p = p0 + lane; p < p1; p += 64) atomicAdd(row + idx[p], val[p]);
+}
+
+void launch_csr_to_dense(hipStream_t s, int rows, const int *ptr, const int *idx, const double *val,
+                         double *dst, int64_t ld) {
+  if (rows)
+    hipLaunchKernelGGL(k_csr_to_dense, dim3((rows + 3) / 4), dim3(256), 0, s, rows, ptr, idx, val,
+                       dst, ld);
+}
+
 // ================================================================ batched kernels
 // Same bodies as above, one instance per blockIdx.z, sizes read on the device (BInst in
 // pgf_internal.h).  Nothing here needs a host round trip.

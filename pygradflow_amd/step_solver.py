@@ -297,18 +297,50 @@ class HipStepSolver:
                 self._push_sparse_derivs()
                 hd.derivs_key = key
             elif key is None or hd.derivs_key is not key:
-                H = _dense_f64(self._hess, (self.n, self.n))
-                J = _dense_f64(self._jac, (self.m, self.n))
-                rc = self._lib.pgf_set_derivs_dense(
-                    hd.h, H.ctypes.data_as(C.c_void_p), max(self.n, 1),
-                    J.ctypes.data_as(C.c_void_p), max(self.n, 1), _lib.PGF_HOST)
-                _lib.check(rc, hd.h, "pgf_set_derivs_dense")
+                if self._csr_upload_pays():
+                    self._push_csr_derivs()
+                else:
+                    H = _dense_f64(self._hess, (self.n, self.n))
+                    J = _dense_f64(self._jac, (self.m, self.n))
+                    rc = self._lib.pgf_set_derivs_dense(
+                        hd.h, H.ctypes.data_as(C.c_void_p), max(self.n, 1),
+                        J.ctypes.data_as(C.c_void_p), max(self.n, 1), _lib.PGF_HOST)
+                    _lib.check(rc, hd.h, "pgf_set_derivs_dense")
                 hd.derivs_key = key
             self._derivs_dirty = False
         if self._mask_dirty:
             mask = np.ascontiguousarray(self.active_set)
             _lib.check(self._lib.pgf_set_active_set(hd.h, _lib.u8ptr(mask)), hd.h, "pgf_set_active_set")
             self._mask_dirty = False
+
+    def _csr_upload_pays(self):
+        """scipy-sparse derivatives with under a quarter of the entries stored: send the
+        non-zeros (12 bytes each) and densify on the device instead of sending n*n doubles."""
+        if not (sps.issparse(self._hess) and (self.m == 0 or sps.issparse(self._jac))):
+            return False
+        nnz = self._hess.nnz + (self._jac.nnz if self.m else 0)
+        return 4 * nnz < self.n * (self.n + self.m)
+
+    def _push_csr_derivs(self):
+        hd = self._hd
+        hess = sps.csr_matrix(self._hess, dtype=np.float64)
+        jac = sps.csr_matrix(self._jac, dtype=np.float64) if self.m else sps.csr_matrix((0, self.n))
+        if hess.shape != (self.n, self.n) or jac.shape != (self.m, self.n):
+            raise ValueError("derivative shapes do not match the problem")
+        ip = C.POINTER(C.c_int)
+
+        def arrs(mat):
+            ptr = np.ascontiguousarray(mat.indptr, dtype=np.int32)
+            idx = np.ascontiguousarray(mat.indices, dtype=np.int32)
+            val = np.ascontiguousarray(mat.data, dtype=np.float64)
+            return ptr, idx, val
+
+        hp, hi, hv = arrs(hess)
+        jp, ji, jv = arrs(jac)
+        rc = self._lib.pgf_set_derivs_csr(
+            hd.h, hp.ctypes.data_as(ip), hi.ctypes.data_as(ip), _lib.dptr(hv),
+            jp.ctypes.data_as(ip), ji.ctypes.data_as(ip), _lib.dptr(jv))
+        _lib.check(rc, hd.h, "pgf_set_derivs_csr")
 
     def _push_sparse_derivs(self):
         hd = self._hd

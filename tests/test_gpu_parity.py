@@ -429,3 +429,70 @@ def test_globalized_policy_and_rcond(pgf, name):
         step = next(gen)
         ref = float(case[f"rcond/{k}"])
         assert step.rcond is not None and abs(step.rcond - ref) <= 1e-8 * ref, (k, step.rcond, ref)
+
+
+def test_csr_upload_equals_dense_upload(pgf, monkeypatch):
+    """pgf_set_derivs_csr (non-zeros over PCIe, densified on device) against
+    pgf_set_derivs_dense for a sparse, non-banded problem: identical steps; duplicate CSR
+    entries are summed like scipy's toarray() does."""
+    import ctypes as C
+
+    from pygradflow_amd import _lib, problems
+    from pygradflow_amd.iterate import Iterate
+    from pygradflow_amd.params import Params
+
+    rng = np.random.default_rng(3)
+    n, m = 300, 80
+    S = sps.random(n, n, density=0.02, random_state=4, format="csr")
+    H = (S + S.T + sps.identity(n) * 4.0).tocsr()
+    J = sps.random(m, n, density=0.05, random_state=5, format="csr")
+    lb, ub = np.full(n, -0.3), np.full(n, 0.4)
+    sparse_prob = problems.LinearQuadraticProblem(H, rng.standard_normal(n), J,
+                                                  rng.standard_normal(m), lb, ub)
+    dense_prob = problems.LinearQuadraticProblem(H.toarray(), sparse_prob.q, J.toarray(),
+                                                 sparse_prob.b, lb, ub)
+    outs, paths = [], []
+    real = pgf.HipStepSolver._csr_upload_pays
+    for prob, force_dense in ((sparse_prob, False), (dense_prob, True)):
+        def pays(self, _force=force_dense):
+            ans = (not _force) and real(self)
+            paths.append(ans)
+            return ans
+
+        monkeypatch.setattr(pgf.HipStepSolver, "_csr_upload_pays", pays)
+        par = Params(newton_type="Full")
+        it = Iterate(prob, par, np.zeros(n), np.zeros(m))
+        gen = pgf.newton_steps(prob, par, it, 0.5, 1.0)
+        steps = [next(gen) for _ in range(3)]
+        outs.append(steps)
+    assert paths[0] is True and paths[-1] is False  # both upload routes were really taken
+    monkeypatch.undo()
+    for a, b in zip(*outs):
+        assert np.array_equal(a.active_set, b.active_set)
+        assert np.array_equal(a.iterate.x, b.iterate.x) and np.array_equal(a.iterate.y, b.iterate.y)
+
+    # duplicates: 2 x 2 system with H[0][0] given as 1.5 + 2.5
+    lib = _lib.load()
+    h = C.c_void_p()
+    _lib.check(lib.pgf_create(2, 0, 0, 0, C.byref(h)))
+    ip = C.POINTER(C.c_int)
+    hp = np.array([0, 3, 4], dtype=np.int32)
+    hi = np.array([0, 1, 0, 1], dtype=np.int32)
+    hv = np.array([1.5, 0.25, 2.5, 3.0])
+    jp = np.zeros(1, dtype=np.int32)
+    rc = lib.pgf_set_derivs_csr(h, hp.ctypes.data_as(ip), hi.ctypes.data_as(ip), _lib.dptr(hv),
+                                jp.ctypes.data_as(ip), None, None)
+    _lib.check(rc, h, "pgf_set_derivs_csr")
+    inf = np.full(2, np.inf)
+    _lib.check(lib.pgf_set_bounds(h, _lib.dptr(-inf), _lib.dptr(inf)), h)
+    _lib.check(lib.pgf_set_outer(h, _lib.dptr(np.zeros(2)), _lib.dptr(np.zeros(0)), 1.0, 1.0), h)
+    _lib.check(lib.pgf_set_active_set(h, _lib.u8ptr(np.zeros(2, dtype=np.bool_))), h)
+    K = np.zeros((2, 2))
+    _lib.check(lib.pgf_get_kkt(h, _lib.dptr(K), 2), h, "pgf_get_kkt")
+    assert K[0, 0] == 1.5 + 2.5 + 1.0 and K[1, 0] == 0.0 and K[1, 1] == 3.0 + 1.0  # + lambda = 1
+    # malformed input is refused
+    bad = np.array([0, 5], dtype=np.int32)
+    rc = lib.pgf_set_derivs_csr(h, hp.ctypes.data_as(ip), bad.ctypes.data_as(ip), _lib.dptr(hv),
+                                jp.ctypes.data_as(ip), None, None)
+    assert rc == _lib.PGF_INVALID
+    lib.pgf_destroy(h)
