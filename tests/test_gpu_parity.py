@@ -449,8 +449,10 @@ def test_csr_upload_equals_dense_upload(pgf, monkeypatch):
     lb, ub = np.full(n, -0.3), np.full(n, 0.4)
     sparse_prob = problems.LinearQuadraticProblem(H, rng.standard_normal(n), J,
                                                   rng.standard_normal(m), lb, ub)
-    dense_prob = problems.LinearQuadraticProblem(H.toarray(), sparse_prob.q, J.toarray(),
-                                                 sparse_prob.b, lb, ub)
+    # a second object with the same (sparse) data: the host-side callbacks then do the same
+    # arithmetic and only the upload route differs
+    dense_prob = problems.LinearQuadraticProblem(H.copy(), sparse_prob.q, J.copy(), sparse_prob.b,
+                                                 lb, ub)
     outs, paths = [], []
     real = pgf.HipStepSolver._csr_upload_pays
     for prob, force_dense in ((sparse_prob, False), (dense_prob, True)):
