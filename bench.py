@@ -47,6 +47,11 @@ WORKLOADS = {
     "sparse_ocp_n100000_m50000": dict(n=100000, m=50000, batch=1, sparse=True),
     # BASELINE configs[4] as given: tridiagonal box QP, 50 % of the bounds active at the start
     "box_qp_n16384": dict(n=16384, m=0, batch=1, sparse=True, box=True),
+    # variant 5b: the same box QP with a DENSE Q (2 GiB): the H[I, I] gather is
+    # HBM-bound and the reduced system (|I| ~ 8192) goes through the dense factorisation; the
+    # CPU restatement would spend minutes in one sparse LU of a dense 8192^2 matrix, so this
+    # workload reports no cpu_baseline
+    "box_qp_dense_n16384": dict(n=16384, m=0, batch=1, box_dense=True, no_cpu=True),
 }
 
 # HBM peak of MI355X (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.3 TB/s achievable)
@@ -209,7 +214,9 @@ def main():
     if wl["batch"] > 1:
         return bench_batched(args, wl, rank, local_rank, world, dist, torch)
     is_sparse = wl.get("sparse", False)
-    if wl.get("box"):
+    if wl.get("box_dense"):
+        problem = problems.box_qp(n, seed=rank, dense=True)
+    elif wl.get("box"):
         problem = problems.box_qp(n, seed=rank)
         problem.pgf_force_band = True
     elif is_sparse:
@@ -242,7 +249,7 @@ def main():
     # parity of the first step against the CPU restatement (rank 0 only, bounded)
     parity = None
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and not wl.get("no_cpu"):
         rate, recs, csteps, cel = cpu_baseline(problem, args.cpu_seconds)
         dn.step()
         xg, yg = dn.point()
