@@ -342,7 +342,8 @@ def main():
             roof = dict(
                 bound="mfma", kernel="k_ldlt_update", achieved=achieved,
                 peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP64_MFMA_TFLOPS,
-                traffic=pmc_traffic("k_ldlt_update"),
+                traffic=(pmc_traffic("k_ldlt_update")
+                         if args.workload == "dense_qp_n4096_m1024" else None),
                 launches_per_step=pr["update_launches"] / args.steps,
                 avg_launch_us=1e3 * pr["update_ms"] / pr["update_launches"],
                 flops_per_step=pr["update_flops"] / args.steps,
