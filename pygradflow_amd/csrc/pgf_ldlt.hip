@@ -1422,6 +1422,77 @@ __device__ __forceinline__ void ll_accumulate(double4_t (&acc)[2][2], unsigned c
   __syncthreads();  // staging area free again
 }
 
+// Single-instance left-looking panel (PGF_PANEL_LL=1): the fused panel kernel with a prologue
+// that brings the diagonal tile and the workgroup's own tile up to date with the earlier
+// panels of the outer block (MFMA, operands from the L2-resident W and L), so that NO K = 64
+// trailing-update launches are needed between the panels of an outer block.
+template <int NB>
+__global__ __launch_bounds__(256) void k_ldlt_panel_ll(double *__restrict__ K, int64_t ldk,
+                                                       double *__restrict__ W, int64_t ldw,
+                                                       int ob0, int N, int nrows, int c0,
+                                                       double *__restrict__ dvec,
+                                                       double *__restrict__ dinv,
+                                                       int *__restrict__ flags) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[PNL_SMEM];
+  double(*M)[PNL_LD] = reinterpret_cast<double(*)[PNL_LD]>(smem);
+  unsigned char *stg = smem + 128 * PNL_LD * 8;  // the W-tile area is free until (a+)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, l15 = lane & 15, l4 = lane >> 4;
+  const int nb = min(NB, N - c0);
+  const int rbase = c0 + nb + (int)blockIdx.x * 64;
+  const int kp = c0 - ob0;
+  double4_t acc[2][2];
+  // diagonal tile (lower triangle), identity outside the valid part
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+      const int j = wc * 32 + nj * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = wr * 32 + mi * 16 + l4 + 4 * r;
+        acc[mi][nj][r] = (i < nb && j <= i) ? K[(int64_t)(c0 + i) * ldk + c0 + j] : 0.0;
+      }
+    }
+  ll_accumulate(acc, stg, W, ldw, c0, c0 + nb, K, ldk, c0, c0 + nb, ob0, kp);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+      const int j = wc * 32 + nj * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = wr * 32 + mi * 16 + l4 + 4 * r;
+        double v = acc[mi][nj][r];
+        if (i >= nb) v = (i == j) ? 1.0 : 0.0;
+        else if (j > i) v = 0.0;
+        M[i][j] = v;
+      }
+    }
+  // own tile: rows rbase .. rbase + 63, columns c0 .. c0 + nb
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+      const int j = wc * 32 + nj * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = rbase + wr * 32 + mi * 16 + l4 + 4 * r;
+        acc[mi][nj][r] = (i < nrows && j < nb) ? K[(int64_t)i * ldk + c0 + j] : 0.0;
+      }
+    }
+  ll_accumulate(acc, stg, W, ldw, rbase, nrows, K, ldk, c0, c0 + nb, ob0, kp);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        M[64 + wr * 32 + mi * 16 + l4 + 4 * r][wc * 32 + nj * 16 + l15] = acc[mi][nj][r];
+  __syncthreads();
+  panel_body<NB, true>(smem, blockIdx.x, K, ldk, W, ldw, kp, N, nrows, c0, dvec, dinv, flags, 0);
+}
+
 __global__ __launch_bounds__(256) void kb_diag_ll(const BInst *__restrict__ tab, int m, int64_t ldw,
                                                   int wbuf, int ob0, int c0) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[PNL_SMEM];
@@ -1822,6 +1893,8 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
   // panel width: 128 (wide kernel, 32 own rows per workgroup) or 64
   const int pw_env = getenv("PGF_PW") ? atoi(getenv("PGF_PW")) : 64;
   const bool pnl2 = getenv("PGF_PANEL2") != nullptr;  // 64-wide panel through the new body
+  // left-looking panels inside the outer block (no K = 64 update launches); single queue only
+  const bool pnl_ll = getenv("PGF_PANEL_LL") != nullptr && !la && getenv("PGF_FUSE") == nullptr;
   const int PWh = (pw_env == 128 && OB % 128 == 0 && getenv("PGF_FUSE") == nullptr) ? 128 : 64;
   const int OWNh = (PWh == 128) ? 32 : 64;
   // With a second queue active, consecutive kernels of ONE stream were observed to overlap
@@ -1899,6 +1972,10 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
       } else if (pnl2) {
         hipLaunchKernelGGL((k_ldlt_panel2<64, 64>), dim3(npw), dim3(256), 0, sA, f.K, f.ldk, Wb,
                            (int64_t)OB, c0 - ob0, N, nrows, c0, f.dvec, f.dinv, f.flags, skip);
+      } else if (pnl_ll) {
+        hipLaunchKernelGGL(k_ldlt_panel_ll<PGF_NB>, dim3(npw), dim3(256), 0, sA, f.K, f.ldk, Wb,
+                           (int64_t)OB, ob0, N, nrows, c0, f.dvec, f.dinv, f.flags);
+        continue;  // no inner updates: the next panel's prologue applies this one
       } else {
         hipLaunchKernelGGL(k_ldlt_panel<PGF_NB>, dim3(npw), dim3(256), 0, sA, f.K, f.ldk, Wb,
                            (int64_t)OB, c0 - ob0, N, nrows, c0, f.dvec, f.dinv, f.flags, skip);
