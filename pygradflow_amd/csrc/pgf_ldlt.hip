@@ -1422,6 +1422,72 @@ __device__ __forceinline__ void ll_accumulate(double4_t (&acc)[2][2], unsigned c
   __syncthreads();  // staging area free again
 }
 
+// Two tiles that share their B operand (the L rows of the diagonal block): accD uses A rows
+// iD0.., accO uses A rows iO0..; one staging pass and one barrier pair per 16-deep chunk for
+// both.  Staging: 3 x 64 x 18 doubles.
+__device__ __forceinline__ void ll_accumulate2(double4_t (&accD)[2][2], double4_t (&accO)[2][2],
+                                               unsigned char *stg,
+                                               const double *__restrict__ A, int64_t lda, int iD0,
+                                               int iDlim, int iO0, int iOlim,
+                                               const double *__restrict__ Bm, int64_t ldb, int j0,
+                                               int jlim, int kb0, int kp) {
+  constexpr int LD = 18;
+  double(*Ad)[LD] = reinterpret_cast<double(*)[LD]>(stg);
+  double(*Ao)[LD] = reinterpret_cast<double(*)[LD]>(stg + 64 * LD * 8);
+  double(*Bs)[LD] = reinterpret_cast<double(*)[LD]>(stg + 2 * 64 * LD * 8);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, l15 = lane & 15, l4 = lane >> 4;
+  double2_t pd[2], po[2], pb[2];
+  auto fetch = [&](int kk) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int p = q * 256 + tid;
+      const int row = p >> 3, kofs = (p & 7) * 2;
+      double2_t vd = (double2_t){0.0, 0.0}, vo = vd, vb = vd;
+      if (iD0 + row < iDlim)
+        vd = *reinterpret_cast<const double2_t *>(A + (int64_t)(iD0 + row) * lda + kk + kofs);
+      if (iO0 + row < iOlim)
+        vo = *reinterpret_cast<const double2_t *>(A + (int64_t)(iO0 + row) * lda + kk + kofs);
+      if (j0 + row < jlim)
+        vb = *reinterpret_cast<const double2_t *>(Bm + (int64_t)(j0 + row) * ldb + kb0 + kk + kofs);
+      pd[q] = vd;
+      po[q] = vo;
+      pb[q] = vb;
+    }
+  };
+  if (kp > 0) fetch(0);
+  for (int kk = 0; kk < kp; kk += 16) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int p = q * 256 + tid;
+      *reinterpret_cast<double2_t *>(&Ad[p >> 3][(p & 7) * 2]) = -pd[q];
+      *reinterpret_cast<double2_t *>(&Ao[p >> 3][(p & 7) * 2]) = -po[q];
+      *reinterpret_cast<double2_t *>(&Bs[p >> 3][(p & 7) * 2]) = pb[q];
+    }
+    __syncthreads();
+    if (kk + 16 < kp) fetch(kk + 16);
+#pragma unroll
+    for (int ks = 0; ks < 16; ks += 4) {
+      double ad[2], ao[2], b[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        ad[t] = Ad[wr * 32 + t * 16 + l15][ks + l4];
+        ao[t] = Ao[wr * 32 + t * 16 + l15][ks + l4];
+        b[t] = Bs[wc * 32 + t * 16 + l15][ks + l4];
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+          accD[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[mi], b[nj], accD[mi][nj], 0, 0, 0);
+          accO[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao[mi], b[nj], accO[mi][nj], 0, 0, 0);
+        }
+    }
+  }
+  __syncthreads();
+}
+
 // Single-instance left-looking panel (PGF_PANEL_LL=1): the fused panel kernel with a prologue
 // that brings the diagonal tile and the workgroup's own tile up to date with the earlier
 // panels of the outer block (MFMA, operands from the L2-resident W and L), so that NO K = 64
@@ -1441,8 +1507,8 @@ __global__ __launch_bounds__(256) void k_ldlt_panel_ll(double *__restrict__ K, i
   const int nb = min(NB, N - c0);
   const int rbase = c0 + nb + (int)blockIdx.x * 64;
   const int kp = c0 - ob0;
-  double4_t acc[2][2];
-  // diagonal tile (lower triangle), identity outside the valid part
+  double4_t accD[2][2], accO[2][2];
+  // diagonal tile (lower triangle) and own tile (rows rbase .., columns c0 .. c0 + nb)
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -1451,10 +1517,11 @@ __global__ __launch_bounds__(256) void k_ldlt_panel_ll(double *__restrict__ K, i
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = wr * 32 + mi * 16 + l4 + 4 * r;
-        acc[mi][nj][r] = (i < nb && j <= i) ? K[(int64_t)(c0 + i) * ldk + c0 + j] : 0.0;
+        accD[mi][nj][r] = (i < nb && j <= i) ? K[(int64_t)(c0 + i) * ldk + c0 + j] : 0.0;
+        accO[mi][nj][r] = (rbase + i < nrows && j < nb) ? K[(int64_t)(rbase + i) * ldk + c0 + j] : 0.0;
       }
     }
-  ll_accumulate(acc, stg, W, ldw, c0, c0 + nb, K, ldk, c0, c0 + nb, ob0, kp);
+  ll_accumulate2(accD, accO, stg, W, ldw, c0, c0 + nb, rbase, nrows, K, ldk, c0, c0 + nb, ob0, kp);
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -1463,32 +1530,13 @@ __global__ __launch_bounds__(256) void k_ldlt_panel_ll(double *__restrict__ K, i
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = wr * 32 + mi * 16 + l4 + 4 * r;
-        double v = acc[mi][nj][r];
-        if (i >= nb) v = (i == j) ? 1.0 : 0.0;
+        double v = accD[mi][nj][r];
+        if (i >= nb) v = (i == j) ? 1.0 : 0.0;  // identity outside the valid part
         else if (j > i) v = 0.0;
         M[i][j] = v;
+        M[64 + i][j] = accO[mi][nj][r];
       }
     }
-  // own tile: rows rbase .. rbase + 63, columns c0 .. c0 + nb
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int nj = 0; nj < 2; ++nj) {
-      const int j = wc * 32 + nj * 16 + l15;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = rbase + wr * 32 + mi * 16 + l4 + 4 * r;
-        acc[mi][nj][r] = (i < nrows && j < nb) ? K[(int64_t)i * ldk + c0 + j] : 0.0;
-      }
-    }
-  ll_accumulate(acc, stg, W, ldw, rbase, nrows, K, ldk, c0, c0 + nb, ob0, kp);
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        M[64 + wr * 32 + mi * 16 + l4 + 4 * r][wc * 32 + nj * 16 + l15] = acc[mi][nj][r];
   __syncthreads();
   panel_body<NB, true>(smem, blockIdx.x, K, ldk, W, ldw, kp, N, nrows, c0, dvec, dinv, flags, 0);
 }
