@@ -1488,7 +1488,7 @@ __device__ __forceinline__ void ll_accumulate2(double4_t (&accD)[2][2], double4_
   __syncthreads();
 }
 
-// Single-instance left-looking panel (PGF_PANEL_LL=1): the fused panel kernel with a prologue
+// Single-instance left-looking panel (default; PGF_PANEL_LL=0 disables): the fused panel kernel with a prologue
 // that brings the diagonal tile and the workgroup's own tile up to date with the earlier
 // panels of the outer block (MFMA, operands from the L2-resident W and L), so that NO K = 64
 // trailing-update launches are needed between the panels of an outer block.
@@ -1941,10 +1941,12 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
   // panel width: 128 (wide kernel, 32 own rows per workgroup) or 64
   const int pw_env = getenv("PGF_PW") ? atoi(getenv("PGF_PW")) : 64;
   const bool pnl2 = getenv("PGF_PANEL2") != nullptr;  // 64-wide panel through the new body
-  // left-looking panels inside the outer block (no K = 64 update launches); single queue only
-  const bool pnl_ll = getenv("PGF_PANEL_LL") != nullptr && !la && getenv("PGF_FUSE") == nullptr;
   const int PWh = (pw_env == 128 && OB % 128 == 0 && getenv("PGF_FUSE") == nullptr) ? 128 : 64;
   const int OWNh = (PWh == 128) ? 32 : 64;
+  // left-looking panels inside the outer block (no K = 64 update launches): the default on the
+  // single-queue schedule; PGF_PANEL_LL=0 brings the separate inner updates back
+  const bool pnl_ll = !(getenv("PGF_PANEL_LL") && atoi(getenv("PGF_PANEL_LL")) == 0) && !la &&
+                      getenv("PGF_FUSE") == nullptr && PWh == 64 && !pnl2;
   // With a second queue active, consecutive kernels of ONE stream were observed to overlap
   // (the last workgroups of an inner update still running when the next panel started:
   // wrong factors, periodic in 8 workgroups).  An explicit record + wait on the same stream
