@@ -1555,28 +1555,11 @@ __global__ __launch_bounds__(256) void k_ldlt_panel_ll(double *__restrict__ K, i
   const int kp = c0 - ob0;
   // diagonal tile: complete already (bulk updates of earlier outer blocks + the eager
   // updates of this block's earlier panels); identity outside the valid lower triangle
-  {
-    double2_t v[8];  // all loads in flight before the first LDS store
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int p = q * 256 + tid;
-      const int i = p >> 5, c2 = (p & 31) * 2;
-      double2_t t = (double2_t){0.0, 0.0};
-      if (i < nb) {
-        const double *src = K + (int64_t)(c0 + i) * ldk + c0 + c2;
-        if (c2 + 1 <= i) t = *reinterpret_cast<const double2_t *>(src);
-        else if (c2 <= i) t.x = src[0];
-      } else {
-        if (c2 == i) t.x = 1.0;
-        if (c2 + 1 == i) t.y = 1.0;
-      }
-      v[q] = t;
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int p = q * 256 + tid;
-      *reinterpret_cast<double2_t *>(&M[p >> 5][(p & 31) * 2]) = v[q];
-    }
+  for (int p = tid; p < 64 * 64; p += 256) {
+    const int i = p >> 6, j = p & 63;
+    double v = (i == j) ? 1.0 : 0.0;
+    if (i < nb) v = (j <= i) ? K[(int64_t)(c0 + i) * ldk + c0 + j] : 0.0;
+    M[i][j] = v;
   }
   // own tile (rows rbase .., columns c0 .. c0 + nb), brought up to date with the earlier
   // panels of the outer block
