@@ -108,7 +108,7 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
                                            double *__restrict__ W, int64_t ldw, int wofs, int N,
                                            int nrows, int c0, double *__restrict__ dvec,
                                            double *__restrict__ dinv, int *__restrict__ flags,
-                                           int skip, int eager_end = 0) {
+                                           int skip) {
   static_assert(NB == 64, "panel kernel is written for 64-column panels");
   double(*M)[PNL_LD] = reinterpret_cast<double(*)[PNL_LD]>(smem);
   double(*Wt)[PNL_WLD] = reinterpret_cast<double(*)[PNL_WLD]>(smem + 128 * PNL_LD * 8);
@@ -342,52 +342,6 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
         if (neg) atomicAdd(&flags[1], neg);
       }
     }
-  }
-  // ---- eager update of a FUTURE diagonal tile (left-looking schedule): the rows this
-  // workgroup owns are the diagonal block of panel k + 1 + wg; this panel's contribution to
-  // that tile, W_own L_own^T, needs nothing but what is in LDS here, so it is applied now,
-  // once, instead of in the prologue of every workgroup of that later panel.
-  if (eager_end > 0 && nb == NB && rbase < eager_end && rbase < N &&
-      !(wave == 1)) {  // quadrant (0, 1) lies above the diagonal
-    const int wr = wave >> 1, wc = wave & 1;
-    double4_t acc[2][2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int nj = 0; nj < 2; ++nj) {
-        const int gj = rbase + wc * 32 + nj * 16 + l15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int gi = rbase + wr * 32 + mi * 16 + l4 + 4 * r;
-          acc[mi][nj][r] = (gi < N && gj <= gi) ? K[(int64_t)gi * ldk + gj] : 0.0;
-        }
-      }
-#pragma unroll 4
-    for (int ks = 0; ks < 64; ks += 4) {
-      const double dk = dD[ks + l4];
-      double a[2], b[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        a[t] = -(M[64 + wr * 32 + t * 16 + l15][ks + l4] * dk);
-        b[t] = M[64 + wc * 32 + t * 16 + l15][ks + l4];
-      }
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int nj = 0; nj < 2; ++nj)
-          acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
-    }
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int nj = 0; nj < 2; ++nj) {
-        const int gj = rbase + wc * 32 + nj * 16 + l15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int gi = rbase + wr * 32 + mi * 16 + l4 + 4 * r;
-          if (gi < N && gj <= gi) K[(int64_t)gi * ldk + gj] = acc[mi][nj][r];
-        }
-      }
   }
 }
 
@@ -1541,7 +1495,7 @@ __device__ __forceinline__ void ll_accumulate2(double4_t (&accD)[2][2], double4_
 template <int NB>
 __global__ __launch_bounds__(256) void k_ldlt_panel_ll(double *__restrict__ K, int64_t ldk,
                                                        double *__restrict__ W, int64_t ldw,
-                                                       int ob0, int obEnd, int N, int nrows, int c0,
+                                                       int ob0, int N, int nrows, int c0,
                                                        double *__restrict__ dvec,
                                                        double *__restrict__ dinv,
                                                        int *__restrict__ flags) {
@@ -1553,17 +1507,8 @@ __global__ __launch_bounds__(256) void k_ldlt_panel_ll(double *__restrict__ K, i
   const int nb = min(NB, N - c0);
   const int rbase = c0 + nb + (int)blockIdx.x * 64;
   const int kp = c0 - ob0;
-  // diagonal tile: complete already (bulk updates of earlier outer blocks + the eager
-  // updates of this block's earlier panels); identity outside the valid lower triangle
-  for (int p = tid; p < 64 * 64; p += 256) {
-    const int i = p >> 6, j = p & 63;
-    double v = (i == j) ? 1.0 : 0.0;
-    if (i < nb) v = (j <= i) ? K[(int64_t)(c0 + i) * ldk + c0 + j] : 0.0;
-    M[i][j] = v;
-  }
-  // own tile (rows rbase .., columns c0 .. c0 + nb), brought up to date with the earlier
-  // panels of the outer block
-  double4_t acc[2][2];
+  double4_t accD[2][2], accO[2][2];
+  // diagonal tile (lower triangle) and own tile (rows rbase .., columns c0 .. c0 + nb)
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -1571,21 +1516,29 @@ __global__ __launch_bounds__(256) void k_ldlt_panel_ll(double *__restrict__ K, i
       const int j = wc * 32 + nj * 16 + l15;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = rbase + wr * 32 + mi * 16 + l4 + 4 * r;
-        acc[mi][nj][r] = (i < nrows && j < nb) ? K[(int64_t)i * ldk + c0 + j] : 0.0;
+        const int i = wr * 32 + mi * 16 + l4 + 4 * r;
+        accD[mi][nj][r] = (i < nb && j <= i) ? K[(int64_t)(c0 + i) * ldk + c0 + j] : 0.0;
+        accO[mi][nj][r] = (rbase + i < nrows && j < nb) ? K[(int64_t)(rbase + i) * ldk + c0 + j] : 0.0;
       }
     }
-  ll_accumulate(acc, stg, W, ldw, rbase, nrows, K, ldk, c0, c0 + nb, ob0, kp);
+  ll_accumulate2(accD, accO, stg, W, ldw, c0, c0 + nb, rbase, nrows, K, ldk, c0, c0 + nb, ob0, kp);
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int nj = 0; nj < 2; ++nj)
+    for (int nj = 0; nj < 2; ++nj) {
+      const int j = wc * 32 + nj * 16 + l15;
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        M[64 + wr * 32 + mi * 16 + l4 + 4 * r][wc * 32 + nj * 16 + l15] = acc[mi][nj][r];
+      for (int r = 0; r < 4; ++r) {
+        const int i = wr * 32 + mi * 16 + l4 + 4 * r;
+        double v = accD[mi][nj][r];
+        if (i >= nb) v = (i == j) ? 1.0 : 0.0;  // identity outside the valid part
+        else if (j > i) v = 0.0;
+        M[i][j] = v;
+        M[64 + i][j] = accO[mi][nj][r];
+      }
+    }
   __syncthreads();
-  panel_body<NB, true>(smem, blockIdx.x, K, ldk, W, ldw, kp, N, nrows, c0, dvec, dinv, flags, 0,
-                       obEnd);
+  panel_body<NB, true>(smem, blockIdx.x, K, ldk, W, ldw, kp, N, nrows, c0, dvec, dinv, flags, 0);
 }
 
 __global__ __launch_bounds__(256) void kb_diag_ll(const BInst *__restrict__ tab, int m, int64_t ldw,
@@ -2071,7 +2024,7 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
                            (int64_t)OB, c0 - ob0, N, nrows, c0, f.dvec, f.dinv, f.flags, skip);
       } else if (pnl_ll) {
         hipLaunchKernelGGL(k_ldlt_panel_ll<PGF_NB>, dim3(npw), dim3(256), 0, sA, f.K, f.ldk, Wb,
-                           (int64_t)OB, ob0, obEnd, N, nrows, c0, f.dvec, f.dinv, f.flags);
+                           (int64_t)OB, ob0, N, nrows, c0, f.dvec, f.dinv, f.flags);
         continue;  // no inner updates: the next panel's prologue applies this one
       } else {
         hipLaunchKernelGGL(k_ldlt_panel<PGF_NB>, dim3(npw), dim3(256), 0, sA, f.K, f.ldk, Wb,
