@@ -15,6 +15,8 @@
 //                       (the FP64-MFMA-bound kernel the roofline is quoted on)
 //   k_inv_diag_blocks   inverse of every 64 x 64 diagonal block of L (once per factor)
 //   k_trsv_{fwd,bwd}_super  triangular solves, 256-row super-blocks per launch
+#include <hip/hip_ext.h>
+
 #include "pgf_internal.h"
 
 #include <algorithm>
@@ -1892,6 +1894,91 @@ static void launch_update(DenseLdlt &f, hipStream_t s, const double *Wp, int64_t
   }
 }
 
+// ------------------------------------------------------------------ overlapped schedule
+// Look-ahead inside ONE queue.  A kernel launched with hipExtAnyOrderLaunch does not wait for
+// the packets before it (tools/launch_gap_test.hip: it really runs unordered on this stack),
+// so after every panel launch of outer block i + 1 a PIECE of outer block i's bulk trailing
+// update is launched any-order and runs beside that panel:
+//     U_next(i)                      columns of block i + 1, normal launch
+//     P0(i+1) | piece 0 of B_i       P0 normal, the piece any-order
+//     P1(i+1) | piece 1 of B_i       P1's barrier waits for P0 AND piece 0, then both start
+//     ...
+//     fence kernel                   normal; its end-of-kernel release writes the last
+//                                    piece's C tiles back before the next block reads them
+// The pieces touch only columns >= nextEnd, the panels of block i + 1 only their own columns
+// and the other W buffer, so a pair never shares data.  Everything a piece reads was written
+// at least two ordinary kernel boundaries earlier; only the panels, which hand data from one
+// to the next across XCDs, keep the ordinary (fenced) launch.
+__global__ void k_fence() {}
+
+static void launch_piece(DenseLdlt &f, hipStream_t s, const double *Wp, int64_t ldw, int N,
+                         int row_lo, int row_hi, int col0, int kc0, int KB) {
+  if (row_lo >= row_hi || col0 >= N) return;
+  const int tr = (row_hi - row_lo + 63) / 64;
+  const int tc = (std::min(N, row_hi) - col0 + 63) / 64;
+  if (tc <= 0) return;
+  hipExtLaunchKernelGGL((k_ldlt_update<64, 64, 16>), dim3(tc, tr), dim3(256), 0, s, nullptr,
+                        nullptr, hipExtAnyOrderLaunch, f.K, f.ldk, Wp, ldw, N, row_hi, row_lo, col0,
+                        N, kc0, KB);
+}
+
+static void factor_overlapped(DenseLdlt &f, int N, int nrows) {
+  hipStream_t s = f.stream;
+  const int OB = f.OB;
+  struct {
+    bool active = false;
+    const double *Wp = nullptr;
+    int reg0 = 0, kc0 = 0, KB = 0, np = 0;
+    int rb[9] = {0};  // row boundaries of the pieces (absolute rows)
+  } pend;
+  int buf = 0;
+  for (int ob0 = 0; ob0 < N; ob0 += OB, buf ^= 1) {
+    const int obEnd = std::min(ob0 + OB, N);
+    double *Wb = f.W + (size_t)buf * f.wstride;
+    const int npanels = (obEnd - ob0 + PGF_NB - 1) / PGF_NB;
+    int k = 0;
+    for (int c0 = ob0; c0 < obEnd; c0 += PGF_NB, ++k) {
+      const int below = nrows - std::min(c0 + PGF_NB, N);
+      const int npw = std::max(1, (below + 63) / 64);
+      hipLaunchKernelGGL(k_ldlt_panel_ll<PGF_NB>, dim3(npw), dim3(256), 0, s, f.K, f.ldk, Wb,
+                         (int64_t)OB, ob0, N, nrows, c0, f.dvec, f.dinv, f.flags);
+      if (pend.active) {
+        // piece k; the last panel of the block takes every piece that is left
+        const int q0 = k, q1 = (k == npanels - 1) ? pend.np : k + 1;
+        for (int q = q0; q < q1 && q < pend.np; ++q)
+          launch_piece(f, s, pend.Wp, OB, N, pend.rb[q], pend.rb[q + 1], pend.reg0, pend.kc0,
+                       pend.KB);
+      }
+    }
+    if (pend.active) hipLaunchKernelGGL(k_fence, dim3(1), dim3(64), 0, s);
+    pend.active = false;
+    if (obEnd < N) {
+      const int KB = obEnd - ob0;
+      const int nextEnd = std::min(obEnd + OB, N);
+      // the next block's columns: needed by its panels, ordinary launch
+      launch_update(f, s, Wb, OB, N, nrows, obEnd, obEnd, nextEnd, ob0, KB, nullptr, 0);
+      if (nextEnd < N) {
+        pend.active = true;
+        pend.Wp = Wb;
+        pend.reg0 = nextEnd;
+        pend.kc0 = ob0;
+        pend.KB = KB;
+        const int nextPanels = (std::min(nextEnd + OB, N) - nextEnd + PGF_NB - 1) / PGF_NB;
+        pend.np = std::max(1, std::min(4, nextPanels));
+        // equal tile counts per piece on the triangular region: boundaries ~ TR sqrt(q / np)
+        const int TR = (nrows - nextEnd + 63) / 64;
+        pend.rb[0] = nextEnd;
+        for (int q = 1; q < pend.np; ++q) {
+          int t = (int)std::lround(TR * std::sqrt((double)q / pend.np));
+          t = std::max(1, std::min(TR, t));
+          pend.rb[q] = std::min(nrows, nextEnd + t * 64);
+        }
+        pend.rb[pend.np] = nrows;
+      }
+    }
+  }
+}
+
 // Two-level right-looking factorisation.
 //   outer block (f.OB columns):  inner 64-column panels
 //                                inner updates restricted to the outer block, K = 64
@@ -1910,6 +1997,18 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
   if (p) {
     p->factor_spans.emplace_back(prof_event(p), prof_event(p));
     (void)hipEventRecord(p->factor_spans.back().first, sA);
+  }
+  // PGF_OVERLAP=1: any-order look-ahead inside the one queue (factor_overlapped); the
+  // instrumented pass (events around every update launch) keeps the plain schedule
+  if (getenv("PGF_OVERLAP") && atoi(getenv("PGF_OVERLAP")) != 0 && !p &&
+      !getenv("PGF_LOOKAHEAD") && !getenv("PGF_FUSE")) {
+    factor_overlapped(f, N, nrows);
+    if (N > 0)
+      hipLaunchKernelGGL(k_inv_diag_blocks, dim3((N + 63) / 64), dim3(64), 0, sA, f.K, f.ldk, N,
+                         f.Linv, f.LinvT);
+    e = hipMemcpyAsync(f.h_flags, f.flags, 2 * sizeof(int), hipMemcpyDeviceToHost, sA);
+    if (e != hipSuccess) return e;
+    return hipGetLastError();
   }
   const int OB = f.OB;
   // PGF_LOOKAHEAD=1: bulk update of outer block i on a second stream, overlapped with the
