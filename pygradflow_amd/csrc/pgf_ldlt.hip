@@ -1923,57 +1923,56 @@ static void launch_piece(DenseLdlt &f, hipStream_t s, const double *Wp, int64_t 
 }
 
 static void factor_overlapped(DenseLdlt &f, int N, int nrows) {
+  // Per outer block i (bulk update B_i = strip A: the next block's columns, + far region):
+  //   A (ordinary) | B1 (any-order)   the strip alone under-fills the chip; B1 = the first
+  //                                    ~FILL tiles of the far region runs beside it
+  //   P0 (ordinary: waits for A, B1) | B2 (any-order) = the rest of the far region
+  //   P1 (ordinary: waits for P0, B2), P2, P3
+  // Ordinary launches end with a cache release, and each one here starts only after the
+  // any-order piece before it has completed, so every piece's C tiles are written back
+  // before anything reads them.
   hipStream_t s = f.stream;
   const int OB = f.OB;
+  const int FILL = getenv("PGF_OVERLAP_FILL") ? atoi(getenv("PGF_OVERLAP_FILL")) : 1000;
   struct {
     bool active = false;
     const double *Wp = nullptr;
-    int reg0 = 0, kc0 = 0, KB = 0, np = 0;
-    int rb[9] = {0};  // row boundaries of the pieces (absolute rows)
+    int reg0 = 0, kc0 = 0, KB = 0, r1 = 0;
   } pend;
   int buf = 0;
   for (int ob0 = 0; ob0 < N; ob0 += OB, buf ^= 1) {
     const int obEnd = std::min(ob0 + OB, N);
     double *Wb = f.W + (size_t)buf * f.wstride;
-    const int npanels = (obEnd - ob0 + PGF_NB - 1) / PGF_NB;
     int k = 0;
     for (int c0 = ob0; c0 < obEnd; c0 += PGF_NB, ++k) {
       const int below = nrows - std::min(c0 + PGF_NB, N);
       const int npw = std::max(1, (below + 63) / 64);
       hipLaunchKernelGGL(k_ldlt_panel_ll<PGF_NB>, dim3(npw), dim3(256), 0, s, f.K, f.ldk, Wb,
                          (int64_t)OB, ob0, N, nrows, c0, f.dvec, f.dinv, f.flags);
-      if (pend.active) {
-        // piece k; the last panel of the block takes every piece that is left
-        const int q0 = k, q1 = (k == npanels - 1) ? pend.np : k + 1;
-        for (int q = q0; q < q1 && q < pend.np; ++q)
-          launch_piece(f, s, pend.Wp, OB, N, pend.rb[q], pend.rb[q + 1], pend.reg0, pend.kc0,
-                       pend.KB);
+      if (k == 0 && pend.active) {  // B2 of the previous block beside this block's first panel
+        launch_piece(f, s, pend.Wp, OB, N, pend.r1, nrows, pend.reg0, pend.kc0, pend.KB);
+        pend.active = false;
       }
     }
-    if (pend.active) hipLaunchKernelGGL(k_fence, dim3(1), dim3(64), 0, s);
-    pend.active = false;
     if (obEnd < N) {
       const int KB = obEnd - ob0;
       const int nextEnd = std::min(obEnd + OB, N);
-      // the next block's columns: needed by its panels, ordinary launch
-      launch_update(f, s, Wb, OB, N, nrows, obEnd, obEnd, nextEnd, ob0, KB, nullptr, 0);
+      launch_update(f, s, Wb, OB, N, nrows, obEnd, obEnd, nextEnd, ob0, KB, nullptr, 0);  // A
       if (nextEnd < N) {
-        pend.active = true;
-        pend.Wp = Wb;
-        pend.reg0 = nextEnd;
-        pend.kc0 = ob0;
-        pend.KB = KB;
-        const int nextPanels = (std::min(nextEnd + OB, N) - nextEnd + PGF_NB - 1) / PGF_NB;
-        pend.np = std::max(1, std::min(4, nextPanels));
-        // equal tile counts per piece on the triangular region: boundaries ~ TR sqrt(q / np)
+        // far region: rows / columns >= nextEnd; B1 = its first tile rows holding ~FILL tiles
         const int TR = (nrows - nextEnd + 63) / 64;
-        pend.rb[0] = nextEnd;
-        for (int q = 1; q < pend.np; ++q) {
-          int t = (int)std::lround(TR * std::sqrt((double)q / pend.np));
-          t = std::max(1, std::min(TR, t));
-          pend.rb[q] = std::min(nrows, nextEnd + t * 64);
+        int t1 = (int)std::ceil((std::sqrt(8.0 * FILL + 1.0) - 1.0) * 0.5);
+        t1 = std::max(1, std::min(TR, t1));
+        const int r1 = std::min(nrows, nextEnd + t1 * 64);
+        launch_piece(f, s, Wb, OB, N, nextEnd, r1, nextEnd, ob0, KB);  // B1
+        if (r1 < nrows) {
+          pend.active = true;
+          pend.Wp = Wb;
+          pend.reg0 = nextEnd;
+          pend.kc0 = ob0;
+          pend.KB = KB;
+          pend.r1 = r1;
         }
-        pend.rb[pend.np] = nrows;
       }
     }
   }
