@@ -1141,7 +1141,7 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_super(const double *__restrict
 //    synchronisation: the call fails loudly and the chained solves are switched off.
 //  * Termination: polls are bounded, every workgroup walks a finite loop, and a workgroup only
 //    waits for workers with a SMALLER index, which are dispatched before it.
-#define CHAIN_SPIN_LIMIT (1 << 22)
+#define CHAIN_SPIN_LIMIT (1 << 18)  // ~0.15 s per wait; a real hand-over takes microseconds
 
 __device__ __forceinline__ void chain_wait(const int *stamp, int epoch, int *ctl) {
   for (int it = 0; it < CHAIN_SPIN_LIMIT; ++it) {
