@@ -512,6 +512,71 @@ __device__ __forceinline__ void bcr_reduce_block(double *__restrict__ D, double 
   if (lane < 8) F[(int64_t)i * 8 + lane] = fv;
 }
 
+// One level in ONE launch: kept block i inverts its two eliminated neighbours itself (each
+// eliminated block is inverted twice, by its left and by its right kept neighbour -- 2 x 1.5 us
+// of redundant work against a dependent launch of ~5 us per level) and then reduces.  The
+// left kept neighbour of an eliminated block always exists, so IT stores the inverse for the
+// back-substitution and reports the block's pivots.
+__device__ __forceinline__ void bcr_level_block(double *__restrict__ D, double *__restrict__ L,
+                                                double *__restrict__ U, double *__restrict__ F,
+                                                double *__restrict__ Dinv, int nb, int s, int i,
+                                                int lane, double *sm, int *__restrict__ flags,
+                                                int *__restrict__ negcnt) {
+  double *A = sm, *B = sm + 64, *T = sm + 128, *fs = sm + 192;
+  const int r = lane >> 3, c = lane & 7;
+  double dv = D[(int64_t)i * 64 + lane];
+  double fv = (lane < 8) ? F[(int64_t)i * 8 + lane] : 0.0;
+  double lnew = 0.0, unew = 0.0;
+  const int le = i - s, ri = i + s;
+  if (le >= 0) {
+    A[lane] = L[(int64_t)i * 64 + lane];
+    B[lane] = D[(int64_t)le * 64 + lane];
+    int bad = 0;
+    (void)gj_inverse8(B, lane, &bad);   // reported by the kept block to the left of `le`
+    const double al = mm8(A, B, r, c);  // alpha = L_i inv(D_left)
+    T[lane] = al;
+    B[lane] = U[(int64_t)le * 64 + lane];
+    if (lane < 8) fs[lane] = F[(int64_t)le * 8 + lane];
+    dv -= mm8(T, B, r, c);              // D_i -= alpha U_left
+    if (lane < 8) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc = fma(T[lane * 8 + k], fs[k], acc);
+      fv -= acc;                        // f_i -= alpha f_left
+    }
+    B[lane] = L[(int64_t)le * 64 + lane];
+    lnew = -mm8(T, B, r, c);            // couples i to i - 2s
+  }
+  if (ri < nb) {
+    A[lane] = U[(int64_t)i * 64 + lane];
+    B[lane] = D[(int64_t)ri * 64 + lane];
+    int bad = 0;
+    const int neg = gj_inverse8(B, lane, &bad);
+    Dinv[(int64_t)ri * 64 + lane] = B[lane];
+    if (lane == 0) {
+      if (bad) atomicOr(&flags[0], 1);
+      negcnt[ri] = neg;
+    }
+    const double ga = mm8(A, B, r, c);  // gamma = U_i inv(D_right)
+    T[lane] = ga;
+    B[lane] = L[(int64_t)ri * 64 + lane];
+    if (lane < 8) fs[lane] = F[(int64_t)ri * 8 + lane];
+    dv -= mm8(T, B, r, c);              // D_i -= gamma L_right
+    if (lane < 8) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc = fma(T[lane * 8 + k], fs[k], acc);
+      fv -= acc;
+    }
+    B[lane] = U[(int64_t)ri * 64 + lane];
+    unew = -mm8(T, B, r, c);            // couples i to i + 2s
+  }
+  D[(int64_t)i * 64 + lane] = dv;
+  L[(int64_t)i * 64 + lane] = lnew;
+  U[(int64_t)i * 64 + lane] = unew;
+  if (lane < 8) F[(int64_t)i * 8 + lane] = fv;
+}
+
 // x_i = inv(D_i) (f_i - L_i x_{i-s} - U_i x_{i+s});  s == 0: the last remaining block
 __device__ __forceinline__ void bcr_back_block(const double *__restrict__ Dinv,
                                                const double *__restrict__ L,
@@ -564,6 +629,18 @@ __global__ __launch_bounds__(64) void k_bcr_reduce(double *__restrict__ D, doubl
   const int i = blockIdx.x * 2 * s;
   if (i >= nb) return;
   bcr_reduce_block(D, L, U, F, Dinv, nb, s, i, threadIdx.x, sm);
+}
+
+// invert + reduce of one level (blocks 0, 2s, 4s, ... are kept)
+__global__ __launch_bounds__(64) void k_bcr_level(double *__restrict__ D, double *__restrict__ L,
+                                                  double *__restrict__ U, double *__restrict__ F,
+                                                  double *__restrict__ Dinv, int nb, int s,
+                                                  int *__restrict__ flags,
+                                                  int *__restrict__ negcnt) {
+  __shared__ double sm[BCR_SCRATCH];
+  const int i = blockIdx.x * 2 * s;
+  if (i >= nb) return;
+  bcr_level_block(D, L, U, F, Dinv, nb, s, i, threadIdx.x, sm, flags, negcnt);
 }
 
 // back-substitution of the blocks eliminated at this level (i mod 2s == s)
@@ -667,15 +744,22 @@ void sp_launch_bcr_solve(hipStream_t s, const SparseDev &sp, int N, int *flags) 
                      sp.bD, sp.bL, sp.bU, sp.bF);
   // levels with many blocks: one workgroup per block; from the first level with at most
   // BCR_TAIL_BLOCKS blocks left: everything in one workgroup, in LDS
+  // PGF_BCR_FUSED=0: separate invert / reduce launches per level
+  static const bool fused_levels = !(getenv("PGF_BCR_FUSED") && atoi(getenv("PGF_BCR_FUSED")) == 0);
   int st = 1;
   for (; st < nb; st *= 2) {
     const int left = (nb + st - 1) / st;  // blocks still in play before this level
     if (left <= BCR_TAIL_BLOCKS) break;
+    const int nk = (nb + 2 * st - 1) / (2 * st);       // kept: 0, 2st, ...
+    if (fused_levels) {
+      hipLaunchKernelGGL(k_bcr_level, dim3(nk), dim3(64), 0, s, sp.bD, sp.bL, sp.bU, sp.bF,
+                         sp.bDinv, nb, st, flags, sp.bneg);
+      continue;
+    }
     const int ne = (nb - st + 2 * st - 1) / (2 * st);  // eliminated: st, 3st, ...
     if (ne > 0)
       hipLaunchKernelGGL(k_bcr_invert, dim3(ne), dim3(64), 0, s, sp.bD, sp.bDinv, nb, st, st,
                          2 * st, flags, sp.bneg);
-    const int nk = (nb + 2 * st - 1) / (2 * st);       // kept: 0, 2st, ...
     hipLaunchKernelGGL(k_bcr_reduce, dim3(nk), dim3(64), 0, s, sp.bD, sp.bL, sp.bU, sp.bF, sp.bDinv,
                        nb, st);
   }
