@@ -233,8 +233,12 @@ def main():
     def one_step(i):
         if i % 2 == 0 and i > 0:
             dn.advance_outer()
-        dn.step()
+        # the step is enqueued, the residual norm of the new point is enqueued behind it, and
+        # ONE host synchronisation (inside residual_norm) covers both; sync() then only reads
+        # the factorisation's status words
+        dn.step_async()
         dn.residual_norm(norms_local.data_ptr())
+        dn.sync()
         if dist is not None:
             dist.all_gather_into_tensor(norms_all, norms_local)  # the one collective / step
             # keep one queue active at a time for the solver (look-ahead)
