@@ -498,3 +498,42 @@ def test_csr_upload_equals_dense_upload(pgf, monkeypatch):
                                 jp.ctypes.data_as(ip), None, None)
     assert rc == _lib.PGF_INVALID
     lib.pgf_destroy(h)
+
+
+def test_device_batch_edge_sizes(pgf):
+    """Batch edge cases named in SURVEY.md 8a: m = 0, and an instance whose variables are ALL
+    active (K is 0 x 0, the step is pure projection) next to ordinary ones; batch sizes that
+    are not a multiple of the 8 XCDs (1 and 3)."""
+    from pygradflow_amd import problems
+    from pygradflow_amd.batched import BatchedDeviceNewton
+
+    n = 96
+
+    def make(i):
+        rng = np.random.default_rng(100 + i)
+        G_ = rng.standard_normal((n, n)) / np.sqrt(n)
+        Q = G_ @ G_.T + np.eye(n)
+        q = 5.0 * rng.standard_normal(n)
+        bound = 1e-3 if i == 1 else 0.5  # instance 1: every variable ends up on a bound
+        return problems.LinearQuadraticProblem(Q, q, np.zeros((0, n)), np.zeros(0),
+                                               np.full(n, -bound), np.full(n, bound))
+
+    for B in (1, 3):
+        bd = BatchedDeviceNewton(make, B, "Full", 1.0, 1.0)
+        ref = BatchedDeviceNewton(make, B, "Full", 1.0, 1.0, sequential=True)
+        for s in ref.solvers:
+            s.advance_outer(1.0, 1.0)
+        for k in range(3):
+            st, nn, df = bd.step_local()
+            st2, nn2, df2 = ref.step_local()
+            assert not st.any() and np.array_equal(nn, nn2) and (nn == 0).all()
+            mk, mk2 = bd.masks(), ref.masks()
+            assert np.array_equal(mk, mk2), (B, k)
+            x, _ = bd.points()
+            x2, _ = ref.points()
+            assert G.rel_err(x, x2) <= 1e-11, (B, k)
+            assert np.allclose(df, df2, rtol=1e-9, atol=1e-12)
+        if B == 3:
+            assert mk[1].all()  # the all-active instance really occurred
+        bd.close()
+        ref.close()
