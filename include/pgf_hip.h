@@ -196,6 +196,16 @@ int pgf_batch_destroy(pgf_batch b);
 const char *pgf_batch_last_error(pgf_batch b);
 /* pgf_qp_advance_outer for every instance: (x^, y^) <- (x, y), new dt and rho */
 int pgf_batch_advance_outer(pgf_batch b, double dt, double rho);
+/* the same with per-instance dt[i], rho[i] -- every instance runs its own step-size
+ * controller -- and accept[i]: nonzero (or accept == NULL) = the instance's last steps were
+ * accepted; zero = rejected, the instance goes back to its outer point (x, y) <- (x^, y^) and
+ * retries with the new dt[i] (StepController.compute_step, step_control.py:80-107) */
+int pgf_batch_advance_outer_each(pgf_batch b, const double *dt, const double *rho,
+                                 const uint8_t *accept);
+/* frozen[i] != 0: instance i sits out the following Newton steps until the next
+ * pgf_batch_advance_outer* (the controller's early exits: converged after the first step,
+ * distance_ratio_control.py:36-45, or a failed factorisation); NULL clears all */
+int pgf_batch_set_frozen(pgf_batch b, const uint8_t *frozen);
 /* pgf_qp_update_active_set for every instance (SimplifiedNewtonMethod.__init__) */
 int pgf_batch_update_active_set(pgf_batch b, double tau);
 /* one NewtonMethod.step per instance (policy bits as pgf_qp_step); enqueue only */

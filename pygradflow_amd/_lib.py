@@ -72,6 +72,8 @@ SIGNATURES = {
     "pgf_batch_destroy": (C.c_int, [_h]),
     "pgf_batch_last_error": (C.c_char_p, [_h]),
     "pgf_batch_advance_outer": (C.c_int, [_h, C.c_double, C.c_double]),
+    "pgf_batch_advance_outer_each": (C.c_int, [_h, _dp, _dp, _u8p]),
+    "pgf_batch_set_frozen": (C.c_int, [_h, _u8p]),
     "pgf_batch_update_active_set": (C.c_int, [_h, C.c_double]),
     "pgf_batch_step_async": (C.c_int, [_h, C.c_uint, C.c_double]),
     "pgf_batch_sync": (C.c_int, [_h, _ip, _ip, _dp]),

@@ -100,6 +100,8 @@ class BatchedDeviceNewton:
         self.device = torch.device("cuda", device)
         self.norms = torch.zeros(max(1, self.count), dtype=torch.float64, device=self.device)
         self._b = None
+        self._frozen = None
+        self._outer_points = [s.point() for s in self.solvers] if self.sequential else []
         if self.count and not self.sequential:
             shapes = {(s.n, s.m, s.sparse) for s in self.solvers}
             if len(shapes) != 1 or next(iter(shapes))[2]:
@@ -125,10 +127,57 @@ class BatchedDeviceNewton:
         self.dt = self.dt if dt is None else float(dt)
         self.rho = self.rho if rho is None else float(rho)
         if self._b is None:
-            for s in self.solvers:
+            self._frozen = None
+            for k, s in enumerate(self.solvers):
+                self._outer_points[k] = s.point()
                 s.advance_outer(self.dt, self.rho)
         else:
             self._begin_outer()
+
+    def advance_outer_each(self, dt, rho, accepted=None):
+        """New outer step with per-instance ``dt[i]``, ``rho[i]``; ``accepted[i]`` False sends
+        instance i back to its outer point (a rejected step) before it retries."""
+        dt = np.ascontiguousarray(dt, dtype=np.float64)
+        rho = np.ascontiguousarray(np.broadcast_to(rho, dt.shape), dtype=np.float64)
+        if dt.shape != (self.count,):
+            raise ValueError("one dt per local instance")
+        if self._b is None:
+            for k, s in enumerate(self.solvers):
+                if accepted is not None and not accepted[k]:
+                    s.set_point(*self._outer_points[k])
+                self._outer_points[k] = s.point()
+                s.advance_outer(float(dt[k]), float(rho[k]))
+            return
+        acc = None
+        if accepted is not None:
+            acc = np.ascontiguousarray(accepted, dtype=np.bool_)
+        lib, b = self._lib.load(), self._b
+        self._lib.check(lib.pgf_batch_advance_outer_each(
+            b, self._lib.dptr(dt), self._lib.dptr(rho), self._lib.u8ptr(acc)), batch=b,
+            what="pgf_batch_advance_outer_each")
+        if self.kind == "Simplified":
+            self._lib.check(lib.pgf_batch_update_active_set(b, self.tau), batch=b,
+                            what="pgf_batch_update_active_set")
+
+    def set_frozen(self, frozen=None):
+        """Instances with ``frozen[i]`` True sit out the following Newton steps (until the next
+        ``advance_outer*``).  Device batch only."""
+        if self._b is None:
+            self._frozen = None if frozen is None else np.array(frozen, dtype=bool)
+            return
+        fz = None if frozen is None else np.ascontiguousarray(frozen, dtype=np.bool_)
+        self._lib.check(self._lib.load().pgf_batch_set_frozen(self._b, self._lib.u8ptr(fz)),
+                        batch=self._b, what="pgf_batch_set_frozen")
+
+    def residual_norms_local(self):
+        """Unscaled residual norms of the local instances at their current points (host)."""
+        if self._b is None:
+            return np.array([s.residual_norm() for s in self.solvers])
+        out = np.empty(self.count)
+        self._lib.check(self._lib.load().pgf_batch_residual_norms(self._b, self._lib.dptr(out),
+                                                                   None), batch=self._b,
+                        what="pgf_batch_residual_norms")
+        return out
 
     def step_local(self):
         """One Newton step of every local instance; returns (status, n_neg, diff) arrays.
@@ -141,9 +190,18 @@ class BatchedDeviceNewton:
         if cnt == 0:
             return status, n_neg, diff
         if self._b is None:
+            from .errors import StepSolverError
+
             base = self.norms.data_ptr()
+            frozen = getattr(self, "_frozen", None)
             for k, s in enumerate(self.solvers):
-                diff[k], n_neg[k] = s.step()
+                if frozen is not None and frozen[k]:
+                    continue
+                try:
+                    diff[k], n_neg[k] = s.step()
+                except StepSolverError:
+                    status[k] = self._lib.PGF_SINGULAR
+                    continue
                 s.residual_norm(base + 8 * k)
             return status, n_neg, diff
         lib, b = self._lib.load(), self._b

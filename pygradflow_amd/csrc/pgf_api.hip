@@ -963,6 +963,8 @@ struct pgf_batch_s {
   int *ctl = nullptr, *flags_out = nullptr, *h_flags = nullptr;
   double *diff_out = nullptr, *norm_out = nullptr, *h_diff = nullptr, *h_norm = nullptr;
   double *red4 = nullptr, *meas_out = nullptr, *h_meas = nullptr;
+  double *ps = nullptr, *h_ps = nullptr;      // per-instance [dt, lambda, rho, fact, delta, ...]
+  uint8_t *bytes = nullptr, *h_bytes = nullptr;  // accept / frozen flags on their way to the device
   BatchScalars sc{};
   bool outer_set = false, eval_fresh = false, step_pending = false, have_mask = false;
   bool all_factored = false;
@@ -1023,6 +1025,11 @@ int pgf_batch_create(const pgf_handle *handles, int count, pgf_batch *out) {
                      (size_t)count * 4 * ((h0->n + h0->m + 255) / 256 + 1) * sizeof(double))) !=
           hipSuccess ||
       (e = hipMalloc((void **)&b->meas_out, (size_t)count * 4 * sizeof(double))) != hipSuccess ||
+      (e = hipMalloc((void **)&b->ps, (size_t)count * BPS_STRIDE * sizeof(double))) != hipSuccess ||
+      (e = hipHostMalloc((void **)&b->h_ps, (size_t)count * BPS_STRIDE * sizeof(double))) !=
+          hipSuccess ||
+      (e = hipMalloc((void **)&b->bytes, (size_t)count)) != hipSuccess ||
+      (e = hipHostMalloc((void **)&b->h_bytes, (size_t)count)) != hipSuccess ||
       (e = hipHostMalloc((void **)&b->h_meas, (size_t)count * 4 * sizeof(double))) != hipSuccess ||
       (e = hipHostMalloc((void **)&b->h_flags, (size_t)count * 3 * sizeof(int))) != hipSuccess ||
       (e = hipHostMalloc((void **)&b->h_diff, count * sizeof(double))) != hipSuccess ||
@@ -1069,6 +1076,7 @@ int pgf_batch_create(const pgf_handle *handles, int count, pgf_batch *out) {
     t.pos = h->pos;
     t.counts = h->counts;
     t.ctl = b->ctl + 4 * i;
+    t.ps = b->ps + (size_t)BPS_STRIDE * i;
     t.K = h->fac.K;
     t.ldk = h->fac.ldk;
     t.W = h->fac.W;
@@ -1100,9 +1108,11 @@ int pgf_batch_destroy(pgf_batch b) {
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   for (void *p : {(void *)b->tab, (void *)b->ctl, (void *)b->flags_out, (void *)b->diff_out,
-                  (void *)b->norm_out, (void *)b->red4, (void *)b->meas_out})
+                  (void *)b->norm_out, (void *)b->red4, (void *)b->meas_out, (void *)b->ps,
+                  (void *)b->bytes})
     if (p) (void)hipFree(p);
-  for (void *p : {(void *)b->h_flags, (void *)b->h_diff, (void *)b->h_norm, (void *)b->h_meas})
+  for (void *p : {(void *)b->h_flags, (void *)b->h_diff, (void *)b->h_norm, (void *)b->h_meas,
+                  (void *)b->h_ps, (void *)b->h_bytes})
     if (p) (void)hipHostFree(p);
   for (hipEvent_t e : b->prof.pool) (void)hipEventDestroy(e);
   for (auto &sp : b->prof.update_spans) {
@@ -1120,29 +1130,70 @@ int pgf_batch_stream(pgf_batch b, void **stream_out) {
   return PGF_OK;
 }
 
-int pgf_batch_advance_outer(pgf_batch b, double dt, double rho) {
-  if (!b) return PGF_INVALID;
-  if (!(dt > 0.0) || !(rho > 0.0)) return bfail(b, PGF_INVALID, "dt and rho must be positive");
+// Start a new outer step for every instance with ITS OWN dt_i, rho_i (every instance has its
+// own step-size controller).  accept[i] != 0 (or accept == NULL): (x^, y^) <- (x, y), the
+// last steps were accepted; accept[i] == 0: (x, y) <- (x^, y^), the instance goes back to its
+// outer point and retries with the new dt_i (StepController.compute_step: rejected steps keep
+// the iterate, step_control.py:80-107).
+int pgf_batch_advance_outer_each(pgf_batch b, const double *dt, const double *rho,
+                                 const uint8_t *accept) {
+  if (!b || !dt || !rho) return PGF_INVALID;
   if (b->step_pending) return bfail(b, PGF_NOT_READY, "pgf_batch_sync the previous step first");
+  for (int i = 0; i < b->B; ++i)
+    if (!(dt[i] > 0.0) || !(rho[i] > 0.0))
+      return bfail(b, PGF_INVALID, "dt and rho must be positive");
+  if (accept && !b->outer_set)
+    for (int i = 0; i < b->B; ++i)
+      if (!accept[i]) return bfail(b, PGF_NOT_READY, "nothing to go back to before the first outer step");
   (void)hipSetDevice(b->device);
-  if (rho != b->sc.rho) b->eval_fresh = false;  // g depends on rho
-  b->sc.dt = dt;
-  b->sc.lamb = 1.0 / dt;
-  b->sc.rho = rho;
-  b->sc.fact = 1.0 / (1.0 + b->sc.lamb * rho);
-  b->sc.delta = b->sc.lamb / (1.0 + b->sc.lamb * rho);
-  batch_launch_advance(b->stream, b->tab, b->B, b->sc);
-  for (pgf_handle h : b->hs) {  // keep the handles' host-side view consistent
-    h->dt = dt;
-    h->lamb = b->sc.lamb;
-    h->rho = rho;
-    h->fact = b->sc.fact;
-    h->delta = b->sc.delta;
+  // the pinned staging buffers may still be in flight from the previous call
+  BHIPCHK(b, hipStreamSynchronize(b->stream));
+  for (int i = 0; i < b->B; ++i) {
+    double *p = b->h_ps + (size_t)BPS_STRIDE * i;
+    const double lamb = 1.0 / dt[i];
+    p[BPS_DT] = dt[i];
+    p[BPS_LAMB] = lamb;
+    p[BPS_RHO] = rho[i];
+    p[BPS_FACT] = 1.0 / (1.0 + lamb * rho[i]);
+    p[BPS_DELTA] = lamb / (1.0 + lamb * rho[i]);
+    b->h_bytes[i] = accept ? (accept[i] ? 1 : 0) : 1;
+    pgf_handle h = b->hs[i];  // keep the handles' host-side view consistent
+    h->dt = dt[i];
+    h->lamb = lamb;
+    h->rho = rho[i];
+    h->fact = p[BPS_FACT];
+    h->delta = p[BPS_DELTA];
     h->outer_set = true;
   }
+  BHIPCHK(b, hipMemcpyAsync(b->ps, b->h_ps, (size_t)b->B * BPS_STRIDE * sizeof(double),
+                            hipMemcpyHostToDevice, b->stream));
+  BHIPCHK(b, hipMemcpyAsync(b->bytes, b->h_bytes, (size_t)b->B, hipMemcpyHostToDevice, b->stream));
+  batch_launch_advance(b->stream, b->tab, b->B, b->sc, b->bytes);
+  b->eval_fresh = false;  // g depends on rho, and rejected instances moved
   b->outer_set = true;
   b->have_mask = false;
   b->all_factored = false;
+  BHIPCHK(b, hipGetLastError());
+  return PGF_OK;
+}
+
+int pgf_batch_advance_outer(pgf_batch b, double dt, double rho) {
+  if (!b) return PGF_INVALID;
+  std::vector<double> dts(b->B, dt), rhos(b->B, rho);
+  return pgf_batch_advance_outer_each(b, dts.data(), rhos.data(), nullptr);
+}
+
+// frozen[i] != 0: instance i sits out the following Newton steps (until the next
+// pgf_batch_advance_outer*): the controller's early exits (converged after the first step,
+// failed factorisation) must not move the instance any further.  NULL clears all.
+int pgf_batch_set_frozen(pgf_batch b, const uint8_t *frozen) {
+  if (!b) return PGF_INVALID;
+  if (b->step_pending) return bfail(b, PGF_NOT_READY, "pgf_batch_sync the previous step first");
+  (void)hipSetDevice(b->device);
+  BHIPCHK(b, hipStreamSynchronize(b->stream));
+  for (int i = 0; i < b->B; ++i) b->h_bytes[i] = (frozen && frozen[i]) ? 1 : 0;
+  BHIPCHK(b, hipMemcpyAsync(b->bytes, b->h_bytes, (size_t)b->B, hipMemcpyHostToDevice, b->stream));
+  batch_launch_set_frozen(b->stream, b->tab, b->B, b->bytes);
   BHIPCHK(b, hipGetLastError());
   return PGF_OK;
 }
@@ -1153,23 +1204,13 @@ static void batch_eval(pgf_batch b) {
   b->eval_fresh = true;
 }
 
-static void batch_tau(pgf_batch b, double tau, int *use_tau, double *f_x, double *f_x0,
-                      double *f_d) {
-  // same factors as tau_factors() (implicit_func.py:237-244)
-  pgf_handle h = b->hs[0];
-  tau_factors(h, tau, use_tau, f_x, f_x0, f_d);
-}
-
 int pgf_batch_update_active_set(pgf_batch b, double tau) {
   if (!b) return PGF_INVALID;
   if (!b->outer_set) return bfail(b, PGF_NOT_READY, "pgf_batch_advance_outer first");
   if (b->step_pending) return bfail(b, PGF_NOT_READY, "pgf_batch_sync the previous step first");
   (void)hipSetDevice(b->device);
   batch_eval(b);
-  int use_tau;
-  double f_x, f_x0, f_d;
-  batch_tau(b, tau, &use_tau, &f_x, &f_x0, &f_d);
-  batch_launch_mask(b->stream, b->tab, b->B, b->sc, 1, use_tau, f_x, f_x0, f_d);
+  batch_launch_mask(b->stream, b->tab, b->B, b->sc, 1, tau);
   b->have_mask = true;
   b->all_factored = false;
   BHIPCHK(b, hipGetLastError());
@@ -1188,11 +1229,7 @@ int pgf_batch_step_async(pgf_batch b, unsigned policy, double tau) {
   if (!recompute && force)
     return bfail(b, PGF_INVALID, "batch: PGF_STEP_REFACTOR needs PGF_STEP_RECOMPUTE_MASK");
   batch_eval(b);
-  int use_tau = 0;
-  double f_x = 0, f_x0 = 0, f_d = 0;
-  if (recompute) batch_tau(b, tau, &use_tau, &f_x, &f_x0, &f_d);
-  batch_launch_mask(b->stream, b->tab, b->B, b->sc, recompute ? (force ? 2 : 1) : 0, use_tau, f_x,
-                    f_x0, f_d);
+  batch_launch_mask(b->stream, b->tab, b->B, b->sc, recompute ? (force ? 2 : 1) : 0, tau);
   b->have_mask = true;
   batch_launch_rhs_assemble(b->stream, b->tab, b->B, b->sc);
   const int Nmax = b->n + b->m;

@@ -69,7 +69,9 @@ int ldlt_chain_check(DenseLdlt &f);
 // ordinary solver handle.  Batched kernels pick their instance with blockIdx.z and read the
 // instance's own reduced size N = counts[0] + m on the device, so a whole batched Newton
 // step is enqueued without a host round trip.  ctl: [0] factor this step, [1] factor
-// valid, [2] mask valid.
+// valid, [2] mask valid, [3] frozen (the instance sits this Newton step out).
+// ps: the instance's own outer-step scalars [dt, lambda, rho, fact, delta] -- every instance
+// has its own step-size controller.
 struct BInst {
   const double *H, *J;
   int64_t ldh, ldj;
@@ -78,6 +80,7 @@ struct BInst {
   double *w, *tmpn, *partial, *red;
   uint8_t *mask, *mask_new;
   int *idxI, *idxA, *pos, *counts, *ctl;
+  const double *ps;
   double *K;
   int64_t ldk;
   double *W;
@@ -88,15 +91,23 @@ struct BInst {
 
 struct BatchScalars {
   int n, m;
-  double dt, lamb, rho, fact, delta;
 };
+#define BPS_DT 0
+#define BPS_LAMB 1
+#define BPS_RHO 2
+#define BPS_FACT 3
+#define BPS_DELTA 4
+#define BPS_STRIDE 8
 
 // pgf_kernels.hip
-void batch_launch_advance(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc);
+// accept[i] != 0: (x^, y^) <- (x, y); == 0: (x, y) <- (x^, y^) (a rejected step goes back)
+void batch_launch_advance(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc,
+                          const uint8_t *accept);
+void batch_launch_set_frozen(hipStream_t s, const BInst *tab, int B, const uint8_t *frozen);
 void batch_launch_eval(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc, int nparts);
 // mode 1: adopt mask_new where it differs (or no mask yet); 2: always adopt; 0: keep
 void batch_launch_mask(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc, int mode,
-                       int use_tau, double f_x, double f_x0, double f_d);
+                       double tau);
 void batch_launch_rhs_assemble(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc);
 // flags_out: [3 i] zero-pivot flag, [3 i + 1] negative pivots, [3 i + 2] |I| of instance i
 void batch_launch_step_update(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc,

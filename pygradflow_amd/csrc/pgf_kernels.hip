@@ -5,6 +5,8 @@
 // scipy's anyway and is covered by the 1e-10 iterate tolerance).
 #include "pgf_kernels.h"
 
+#include <algorithm>
+
 #include "pgf_internal.h"
 
 #define ACTIVE_EPS 1e-8  // reference implicit_func.py:44
@@ -718,21 +720,37 @@ void launch_csr_to_dense(hipStream_t s, int rows, const int *ptr, const int *idx
 // ================================================================ batched kernels
 // Same bodies as above, one instance per blockIdx.z, sizes read on the device (BInst in
 // pgf_internal.h).  Nothing here needs a host round trip.
-__global__ void kb_advance(const BInst *__restrict__ tab, int n, int m, double lamb) {
+__global__ void kb_advance(const BInst *__restrict__ tab, int n, int m,
+                           const uint8_t *__restrict__ accept) {
   const BInst &I = tab[blockIdx.z];
+  const double lamb = I.ps[BPS_LAMB];
+  const bool acc = accept[blockIdx.z] != 0;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
-    I.xhat[i] = I.x[i];
+    if (acc)
+      I.xhat[i] = I.x[i];
+    else
+      I.x[i] = I.xhat[i];
     I.slb[i] = lamb * I.lb[i];
     I.sub[i] = lamb * I.ub[i];
   } else if (i < n + m) {
-    I.yhat[i - n] = I.y[i - n];
+    if (acc)
+      I.yhat[i - n] = I.y[i - n];
+    else
+      I.y[i - n] = I.yhat[i - n];
   }
   if (i == 0) {
     I.ctl[0] = 0;
     I.ctl[1] = 0;
     I.ctl[2] = 0;
+    I.ctl[3] = 0;
   }
+}
+
+__global__ void kb_set_frozen(const BInst *__restrict__ tab, int B,
+                              const uint8_t *__restrict__ frozen) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) tab[i].ctl[3] = frozen[i] ? 1 : 0;
 }
 
 // which 0: c = J x - b ; which 1: g = H x + tmpn
@@ -745,9 +763,9 @@ __global__ __launch_bounds__(256) void kb_gemv_rows(const BInst *__restrict__ ta
     b_gemv_rows(n, n, I.H, I.ldh, I.x, I.tmpn, 1.0, I.g);
 }
 
-__global__ void kb_mult_vec(const BInst *__restrict__ tab, int m, double rho) {
+__global__ void kb_mult_vec(const BInst *__restrict__ tab, int m) {
   const BInst &I = tab[blockIdx.z];
-  b_mult_vec(m, rho, I.c, I.y, I.w);
+  b_mult_vec(m, I.ps[BPS_RHO], I.c, I.y, I.w);
 }
 
 __global__ __launch_bounds__(256) void kb_gemvT_partial(const BInst *__restrict__ tab, int n, int m,
@@ -761,9 +779,16 @@ __global__ void kb_sum_partials(const BInst *__restrict__ tab, int n, int used) 
   b_sum_partials(n, used, I.partial, I.q, I.tmpn);
 }
 
-__global__ void kb_active_set(const BInst *__restrict__ tab, int n, int use_tau, double lamb,
-                              double f_x, double f_x0, double f_d) {
+// tau NaN = None; the factors of the tau form exactly as the host computes them for a single
+// instance (implicit_func.py:237-244)
+__global__ void kb_active_set(const BInst *__restrict__ tab, int n, double tau) {
   const BInst &I = tab[blockIdx.z];
+  if (I.ctl[3]) return;
+  const double lamb = I.ps[BPS_LAMB];
+  const int use_tau = (tau != tau) ? 0 : 1;
+  const double f_x = use_tau ? lamb * (1 - tau * lamb) : 0.0;
+  const double f_x0 = use_tau ? tau * lamb * lamb : 0.0;
+  const double f_d = use_tau ? tau * lamb : 0.0;
   b_active_set(n, use_tau, lamb, f_x, f_x0, f_d, I.xhat, I.x, I.g, I.slb, I.sub, I.mask_new);
 }
 
@@ -774,6 +799,10 @@ __global__ __launch_bounds__(1024) void kb_mask_adopt(const BInst *__restrict__ 
                                                       int mode) {
   const BInst &I = tab[blockIdx.z];
   const int tid = threadIdx.x;
+  if (I.ctl[3]) {  // frozen: nothing of this instance moves in this step
+    if (tid == 0) I.ctl[0] = 0;
+    return;
+  }
   int diff = 0;
   if (mode == 2 || (mode == 1 && I.ctl[2] == 0)) {
     diff = 1;
@@ -794,24 +823,27 @@ __global__ __launch_bounds__(1024) void kb_mask_adopt(const BInst *__restrict__ 
   }
 }
 
-__global__ void kb_residual(const BInst *__restrict__ tab, int n, int m, double lamb, double dt) {
+__global__ void kb_residual(const BInst *__restrict__ tab, int n, int m) {
   const BInst &I = tab[blockIdx.z];
+  if (I.ctl[3]) return;
+  const double lamb = I.ps[BPS_LAMB], dt = I.ps[BPS_DT];
   b_residual(n, m, lamb, dt, I.xhat, I.yhat, I.x, I.y, I.g, I.c, I.slb, I.sub, I.mask, I.F,
              I.b0full);
 }
 
-__global__ __launch_bounds__(256) void kb_reduced_rhs(const BInst *__restrict__ tab, int n, int m,
-                                                      double fact) {
+__global__ __launch_bounds__(256) void kb_reduced_rhs(const BInst *__restrict__ tab, int n,
+                                                      int m) {
   const BInst &I = tab[blockIdx.z];
-  b_reduced_rhs(n, m, I.counts[0], I.counts[1], fact, I.F, I.idxI, I.H, I.ldh, I.J, I.ldj,
+  if (I.ctl[3]) return;
+  b_reduced_rhs(n, m, I.counts[0], I.counts[1], I.ps[BPS_FACT], I.F, I.idxI, I.H, I.ldh, I.J, I.ldj,
                 I.b0full, I.rhs);
 }
 
 // K (lower triangle) + the right-hand side in row N, only for instances that factorise
-__global__ __launch_bounds__(256) void kb_assemble(const BInst *__restrict__ tab, int m,
-                                                   double lamb, double delta) {
+__global__ __launch_bounds__(256) void kb_assemble(const BInst *__restrict__ tab, int m) {
   const BInst &I = tab[blockIdx.z];
   if (I.ctl[0] == 0) return;
+  const double lamb = I.ps[BPS_LAMB], delta = I.ps[BPS_DELTA];
   const int nI = I.counts[0], N = nI + m;
   const int i0 = blockIdx.y * ASM_ROWS;
   if (i0 > N) return;
@@ -823,10 +855,11 @@ __global__ __launch_bounds__(256) void kb_assemble(const BInst *__restrict__ tab
   b_assemble_kkt(I.K, I.ldk, I.H, I.ldh, I.J, I.ldj, I.idxI, nI, m, lamb, delta);
 }
 
-__global__ __launch_bounds__(256) void kb_step_update(const BInst *__restrict__ tab, int n, int m,
-                                                      double fact, double rho) {
+__global__ __launch_bounds__(256) void kb_step_update(const BInst *__restrict__ tab, int n,
+                                                      int m) {
   const BInst &I = tab[blockIdx.z];
-  b_step_update(n, m, I.counts[0], fact, rho, I.x, I.y, I.lb, I.ub, I.mask, I.pos, I.b0full, I.F,
+  if (I.ctl[3]) return;
+  b_step_update(n, m, I.counts[0], I.ps[BPS_FACT], I.ps[BPS_RHO], I.x, I.y, I.lb, I.ub, I.mask, I.pos, I.b0full, I.F,
                 I.sol, I.dx, I.dy, I.xn, I.yn, I.red);
   // the new point replaces the current one in place (each lane re-reads its own entry)
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -840,6 +873,15 @@ __global__ __launch_bounds__(256) void kb_step_final(const BInst *__restrict__ t
                                                      double *__restrict__ diff_out,
                                                      int *__restrict__ flags_out) {
   const BInst &I = tab[blockIdx.z];
+  if (I.ctl[3]) {  // frozen: no step was taken
+    if (threadIdx.x == 0) {
+      diff_out[blockIdx.z] = 0.0;
+      flags_out[3 * blockIdx.z] = 0;
+      flags_out[3 * blockIdx.z + 1] = I.flags[1];
+      flags_out[3 * blockIdx.z + 2] = I.counts[0];
+    }
+    return;
+  }
   b_final_reduce(I.red, nb, diff_out + blockIdx.z, 1);
   if (threadIdx.x == 0) {
     flags_out[3 * blockIdx.z] = I.flags[0];
@@ -850,9 +892,9 @@ __global__ __launch_bounds__(256) void kb_step_final(const BInst *__restrict__ t
 }
 
 __global__ __launch_bounds__(256) void kb_unscaled_res_sq(const BInst *__restrict__ tab, int n,
-                                                          int m, double dt) {
+                                                          int m) {
   const BInst &I = tab[blockIdx.z];
-  b_unscaled_res_sq(n, m, dt, I.xhat, I.yhat, I.x, I.y, I.g, I.c, I.lb, I.ub, I.red);
+  b_unscaled_res_sq(n, m, I.ps[BPS_DT], I.xhat, I.yhat, I.x, I.y, I.g, I.c, I.lb, I.ub, I.red);
 }
 
 __global__ __launch_bounds__(256) void kb_norm_final(const BInst *__restrict__ tab, int nb,
@@ -863,10 +905,14 @@ __global__ __launch_bounds__(256) void kb_norm_final(const BInst *__restrict__ t
 
 static inline dim3 gb(int cnt, int per, int B) { return dim3((cnt + per - 1) / per, 1, B); }
 
-void batch_launch_advance(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc) {
-  if (sc.n + sc.m)
-    hipLaunchKernelGGL(kb_advance, gb(sc.n + sc.m, 256, B), dim3(256), 0, s, tab, sc.n, sc.m,
-                       sc.lamb);
+void batch_launch_advance(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc,
+                          const uint8_t *accept) {
+  hipLaunchKernelGGL(kb_advance, gb(std::max(1, sc.n + sc.m), 256, B), dim3(256), 0, s, tab, sc.n,
+                     sc.m, accept);
+}
+
+void batch_launch_set_frozen(hipStream_t s, const BInst *tab, int B, const uint8_t *frozen) {
+  hipLaunchKernelGGL(kb_set_frozen, dim3((B + 255) / 256), dim3(256), 0, s, tab, B, frozen);
 }
 
 // c = A x - b ; w = rho c + y ; tmpn = q + A' w ; g = Q x + tmpn   for every instance
@@ -876,7 +922,7 @@ void batch_launch_eval(hipStream_t s, const BInst *tab, int B, const BatchScalar
   int used = 0;
   if (m) {
     hipLaunchKernelGGL(kb_gemv_rows, gb(m, 4, B), dim3(256), 0, s, tab, 0, n, m);
-    hipLaunchKernelGGL(kb_mult_vec, gb(m, 256, B), dim3(256), 0, s, tab, m, sc.rho);
+    hipLaunchKernelGGL(kb_mult_vec, gb(m, 256, B), dim3(256), 0, s, tab, m);
     const int chunk = (m + nparts - 1) / nparts;
     used = (m + chunk - 1) / chunk;
     hipLaunchKernelGGL(kb_gemvT_partial, dim3((n + 255) / 256, used, B), dim3(256), 0, s, tab, n, m,
@@ -887,29 +933,26 @@ void batch_launch_eval(hipStream_t s, const BInst *tab, int B, const BatchScalar
 }
 
 void batch_launch_mask(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc, int mode,
-                       int use_tau, double f_x, double f_x0, double f_d) {
+                       double tau) {
   if (mode != 0 && sc.n)
-    hipLaunchKernelGGL(kb_active_set, gb(sc.n, 256, B), dim3(256), 0, s, tab, sc.n, use_tau,
-    sc.lamb,
-                       f_x, f_x0, f_d);
+    hipLaunchKernelGGL(kb_active_set, gb(sc.n, 256, B), dim3(256), 0, s, tab, sc.n, tau);
   hipLaunchKernelGGL(kb_mask_adopt, dim3(1, 1, B), dim3(1024), 0, s, tab, sc.n, mode);
 }
 
 void batch_launch_rhs_assemble(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc) {
   const int n = sc.n, m = sc.m, Nmax = n + m;
   if (!Nmax) return;
-  hipLaunchKernelGGL(kb_residual, gb(Nmax, 256, B), dim3(256), 0, s, tab, n, m, sc.lamb, sc.dt);
-  hipLaunchKernelGGL(kb_reduced_rhs, gb(Nmax, 4, B), dim3(256), 0, s, tab, n, m, sc.fact);
+  hipLaunchKernelGGL(kb_residual, gb(Nmax, 256, B), dim3(256), 0, s, tab, n, m);
+  hipLaunchKernelGGL(kb_reduced_rhs, gb(Nmax, 4, B), dim3(256), 0, s, tab, n, m);
   hipLaunchKernelGGL(kb_assemble, dim3((Nmax + 255) / 256, Nmax / ASM_ROWS + 1, B), dim3(256), 0,
-                     s, tab, m, sc.lamb, sc.delta);
+                     s, tab, m);
 }
 
 void batch_launch_step_update(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc,
                               double *diff_out, int *flags_out) {
   const int nb = step_update_blocks(sc.n, sc.m);
   if (nb)
-    hipLaunchKernelGGL(kb_step_update, dim3(nb, 1, B), dim3(256), 0, s, tab, sc.n, sc.m, sc.fact,
-                       sc.rho);
+    hipLaunchKernelGGL(kb_step_update, dim3(nb, 1, B), dim3(256), 0, s, tab, sc.n, sc.m);
   hipLaunchKernelGGL(kb_step_final, dim3(1, 1, B), dim3(256), 0, s, tab, nb, diff_out, flags_out);
 }
 
@@ -917,7 +960,7 @@ void batch_launch_res_norm(hipStream_t s, const BInst *tab, int B, const BatchSc
                            double *norm_out) {
   const int nb = (sc.n + sc.m + 255) / 256;
   if (nb)
-    hipLaunchKernelGGL(kb_unscaled_res_sq, dim3(nb, 1, B), dim3(256), 0, s, tab, sc.n, sc.m, sc.dt);
+    hipLaunchKernelGGL(kb_unscaled_res_sq, dim3(nb, 1, B), dim3(256), 0, s, tab, sc.n, sc.m);
   hipLaunchKernelGGL(kb_norm_final, dim3(1, 1, B), dim3(256), 0, s, tab, nb, norm_out);
 }
 

@@ -1737,7 +1737,7 @@ __global__ __launch_bounds__(64) void kb_inv_diag_blocks(const BInst *__restrict
 // forward half for instances whose factor is reused: zwork <- rhs
 __global__ void kb_solve_prep_fwd(const BInst *__restrict__ tab, int m) {
   const BInst &I = tab[blockIdx.z];
-  if (I.ctl[0] != 0) return;
+  if (I.ctl[0] != 0 || I.ctl[3]) return;
   const int N = I.counts[0] + m;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) I.zwork[i] = I.rhs[i];
@@ -1746,7 +1746,7 @@ __global__ void kb_solve_prep_fwd(const BInst *__restrict__ tab, int m) {
 __global__ __launch_bounds__(256) void kb_trsv_fwd_super(const BInst *__restrict__ tab, int m,
                                                          int c0) {
   const BInst &I = tab[blockIdx.z];
-  if (I.ctl[0] != 0) return;
+  if (I.ctl[0] != 0 || I.ctl[3]) return;
   const int N = I.counts[0] + m;
   if (c0 >= N) return;
   const int below = N - (c0 + 256);
@@ -1758,6 +1758,7 @@ __global__ __launch_bounds__(256) void kb_trsv_fwd_super(const BInst *__restrict
 // zwork <- D^-1 L^-1 rhs: row N of K after a factorisation, D^-1 * (forward result) otherwise
 __global__ void kb_solve_prep_bwd(const BInst *__restrict__ tab, int m) {
   const BInst &I = tab[blockIdx.z];
+  if (I.ctl[3]) return;
   const int N = I.counts[0] + m;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
@@ -1767,6 +1768,7 @@ __global__ void kb_solve_prep_bwd(const BInst *__restrict__ tab, int m) {
 __global__ __launch_bounds__(256) void kb_trsv_bwd_super(const BInst *__restrict__ tab, int m,
                                                          int c0) {
   const BInst &I = tab[blockIdx.z];
+  if (I.ctl[3]) return;
   const int N = I.counts[0] + m;
   if (c0 >= N) return;
   const int g = c0 > 0 ? (c0 + 63) / 64 : 1;

@@ -221,6 +221,62 @@ class DeviceDistanceRatioController:
         return DeviceControlResult(lamb_n, accepted, 2, (first, second), mid_norm)
 
 
+class BatchedDistanceRatioController:
+    """``DistanceRatioController`` for every instance of a ``BatchedDeviceNewton`` at once.
+
+    Each instance keeps its own lambda and its own PI controller; one call of ``step`` is one
+    outer iteration of ALL local instances: a per-instance ``advance_outer`` (rejected
+    instances go back to their outer point), one batched Newton step, the early exits of
+    distance_ratio_control.py:36-45 decided per instance on the host (those instances are
+    frozen for the second step), a second batched Newton step, theta tests and PI updates.
+    The host sees 3 small vectors per outer iteration (two step lengths and a residual norm
+    per instance).
+    """
+
+    def __init__(self, batch, params, rho=None):
+        self.bd = batch
+        self.params = params
+        cnt = batch.count
+        self.lamb = np.full(cnt, float(params.lamb_init))
+        self.rho = np.full(cnt, float(params.rho if rho is None else rho))
+        self.accepted = np.ones(cnt, dtype=bool)
+        self.controllers = [LogController(ControllerSettings.from_params(params), params.theta_ref)
+                            for _ in range(cnt)]
+
+    def step(self):
+        """One outer iteration; returns (lamb_used, lamb_next, accepted) arrays."""
+        bd, params = self.bd, self.params
+        lamb = self.lamb.copy()
+        bd.advance_outer_each(1.0 / lamb, self.rho, self.accepted)  # also clears the frozen flags
+        st1, _, first = bd.step_local()
+        mid = bd.residual_norms_local()
+        cnt = bd.count
+        lamb_n = lamb.copy()
+        accepted = np.ones(cnt, dtype=bool)
+        done = np.zeros(cnt, dtype=bool)
+        failed = st1 != 0
+        lamb_n[failed] = 2.0 * lamb[failed]
+        accepted[failed] = False
+        done |= failed
+        conv = ~done & (mid <= params.newton_tol)
+        lamb_n[conv] = np.maximum(lamb[conv] * params.lamb_red, params.lamb_min)
+        done |= conv
+        done |= ~done & (first == 0.0)  # lamb unchanged, accepted
+        if not done.all():
+            bd.set_frozen(done)
+            st2, _, second = bd.step_local()
+            for i in np.nonzero(~done)[0]:
+                if st2[i] != 0:
+                    lamb_n[i], accepted[i] = 2.0 * lamb[i], False
+                elif second[i] == 0.0:
+                    pass
+                else:
+                    lamb_n[i], accepted[i] = _ratio_decision(self.controllers[i], params, lamb[i],
+                                                             first[i], second[i])
+        self.lamb, self.accepted = lamb_n, accepted
+        return lamb, lamb_n, accepted
+
+
 def gradient_flow(controller, make_iterate, x0, y0, rho, iterations, lamb=None):
     """Minimal outer loop around a host step controller (the accept / lambda bookkeeping of
     ``Solver.solve``, solver.py:300-378, without penalty updates and termination tests).

@@ -170,3 +170,51 @@ def test_device_distance_ratio_controller(pgf, name):
         assert G.rel_err(x, case["x"][k]) <= 1e-8 and G.rel_err(y, case["y"][k]) <= 1e-8, k
         lamb = res.lamb
     dn.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["Full", "Simplified"])
+def test_batched_distance_ratio_controller(pgf, kind):
+    """One controller object driving a whole device batch (per-instance lambda, per-instance
+    accept / reject with restore, early exits as frozen instances) against one
+    DeviceDistanceRatioController per instance: same decisions, same lambdas, same points."""
+    from pygradflow_amd import problems
+    from pygradflow_amd.batched import BatchedDeviceNewton
+
+    B, n, m = 4, 96, 24
+
+    def make(i):
+        return problems.dense_qp(n, m, seed=30 + i, boxed_frac=0.2 + 0.1 * i, box=0.05)
+
+    par = Params(newton_type=kind, lamb_init=1.0 + 0.0)
+    bd = BatchedDeviceNewton(make, B, kind, 1.0, 1.0)
+    bc = SC.BatchedDistanceRatioController(bd, par, rho=1.0)
+    singles = []
+    for i in range(B):
+        dn = pgf.DeviceNewton(make(i), kind, np.zeros(n), np.zeros(m), 1.0, 1.0)
+        singles.append((dn, SC.DeviceDistanceRatioController(dn, par), [par.lamb_init]))
+    rejected_seen = False
+    for it in range(9):
+        lamb_used, lamb_next, acc = bc.step()
+        x, y = bd.points()
+        for i, (dn, ctl, lam) in enumerate(singles):
+            assert lamb_used[i] == pytest.approx(lam[0], rel=1e-6), (it, i)
+            res = ctl.step(1.0, 1.0 / lam[0])
+            assert res.accepted == bool(acc[i]), (it, i)
+            assert res.lamb == pytest.approx(lamb_next[i], rel=1e-6), (it, i)
+            lam[0] = res.lamb
+            if res.accepted:
+                xs, ys = dn.point()
+                assert G.rel_err(x[i], xs) <= 1e-9 and G.rel_err(y[i], ys) <= 1e-9, (it, i)
+            else:
+                rejected_seen = True
+    # one more advance puts rejected instances back on their outer points, as the single
+    # controllers did at once
+    bd.advance_outer_each(1.0 / bc.lamb, bc.rho, bc.accepted)
+    x, y = bd.points()
+    for i, (dn, _, _) in enumerate(singles):
+        xs, ys = dn.point()
+        assert G.rel_err(x[i], xs) <= 1e-9 and G.rel_err(y[i], ys) <= 1e-9, i
+        dn.close()
+    bd.close()
+    assert rejected_seen or kind == "Full"
