@@ -1980,14 +1980,17 @@ static void factor_overlapped(DenseLdlt &f, int N, int nrows) {
   }
 }
 
-// Two-level right-looking factorisation.
-//   outer block (f.OB columns):  inner 64-column panels
-//                                inner updates restricted to the outer block, K = 64
-//   bulk update with K = OB:     next outer block's columns right away (the next panels
-//                                need them); the rest as FILLER tiles carried by the next
-//                                outer block's panel launches (look-ahead inside one queue)
-// W (= L D of the current outer block, OB columns wide) is double buffered because the
-// filler tiles of block i still read it while the panels of block i + 1 write theirs.
+// Two-level factorisation, the schedule of one call (default path, one queue):
+//   per outer block of f.OB = 256 columns:
+//     4 x k_ldlt_panel_ll   64-column panels, left-looking inside the block: a panel's
+//                           prologue applies the earlier panels of the block to the two tiles
+//                           it needs, so nothing is launched between them
+//     1 x k_ldlt_update     bulk right-looking update of everything to the right, K = 256
+//   k_inv_diag_blocks       inverses of the 64 x 64 diagonal blocks for the solves
+// W (= L D of the current outer block, OB columns wide) is double buffered: the experimental
+// overlapped / look-ahead schedules still read block i's W while block i + 1 writes its own.
+// The branches behind PGF_LOOKAHEAD, PGF_FUSE, PGF_OVERLAP, PGF_PANEL_LL=0, PGF_PW and
+// PGF_PANEL2 are the experiments DESIGN.md describes; none of them is the default.
 hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
   f.N = N;
   f.factored = false;
