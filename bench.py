@@ -116,7 +116,7 @@ def bench_batched(args, wl, rank, local_rank, world, dist, torch):
 
     # parity of instance 0's first step against the CPU restatement (rank 0, bounded)
     parity = cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         rate, recs, csteps, cel = cpu_baseline(problems.dense_qp(n, m, seed=0), args.cpu_seconds)
         bd.step_local()
         xg, yg = bd.points()
@@ -253,7 +253,7 @@ def main():
     # parity of the first step against the CPU restatement (rank 0 only, bounded)
     parity = None
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline and not wl.get("no_cpu"):
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not wl.get("no_cpu"):
         rate, recs, csteps, cel = cpu_baseline(problem, args.cpu_seconds)
         dn.step()
         xg, yg = dn.point()
