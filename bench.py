@@ -142,11 +142,13 @@ def bench_batched(args, wl, rank, local_rank, world, dist, torch):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # EVERY rank walks the same steps (each one ends in the all-gather); only rank 0 records
     roof = None
     if rank == 0:
         bd.profile(True)
-        for i in range(args.steps):
-            one_step(i)
+    for i in range(args.steps):
+        one_step(i)
+    if rank == 0:
         pr = bd.profile_read()
         bd.profile(False)
         if pr["update_launches"] > 0 and pr["update_ms"] > 0:
@@ -321,12 +323,14 @@ def main():
         elapsed = float(t.item())
 
     # instrumented pass: HIP events around every trailing-update launch (same steps)
+    # EVERY rank walks the same steps (each one ends in the all-gather); only rank 0 records
     roof = None
+    dn.set_outer(x0, y0, 1.0, 1.0)
     if rank == 0:
-        dn.set_outer(x0, y0, 1.0, 1.0)
         dn.profile(True)
-        for i in range(args.steps):
-            one_step(i)
+    for i in range(args.steps):
+        one_step(i)
+    if rank == 0:
         pr = dn.profile_read()
         dn.profile(False)
         if is_sparse and pr["update_launches"] > 0 and pr["update_ms"] > 0:
