@@ -204,9 +204,16 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        # PGF_BENCH_ONE_GPU=1 (rehearsal of the multi-rank control flow on a one-GPU box): all
+        # ranks share cuda:0 and talk over gloo; never used for reported numbers
+        if os.environ.get("PGF_BENCH_ONE_GPU"):
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     from pygradflow_amd import problems
     from pygradflow_amd.newton import DeviceNewton
