@@ -174,6 +174,7 @@ int pgf_destroy(pgf_handle h) {
   if (!h) return PGF_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  ldlt_chain_timing_dump();
   void *ptrs[] = {h->csr_ptr, h->csr_idx, h->csr_val, h->Hown, h->Jown, h->lb,  h->ub,   h->slb,  h->sub,      h->xhat, h->yhat,
                   h->x,    h->y,    h->xn,  h->yn,   h->g,    h->c,        h->F,    h->b0full,
                   h->rhs,  h->sol,  h->dx,  h->dy,   h->q,    h->b,        h->w,    h->tmpn,

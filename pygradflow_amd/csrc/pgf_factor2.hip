@@ -1,0 +1,846 @@
+// Look-ahead schedule of the dense LDL^T factorisation of the reduced KKT matrix (the default;
+// replaces SuperLU gstrf reached through scipy.sparse.linalg.splu at reference
+// pygradflow/linear_solver/lu_solver.py:14).  Same arithmetic as pgf_ldlt.hip (unpivoted
+// right-looking LDL^T in the natural order, inertia = number of negative pivots), different
+// division of labour.  Per outer block k of 256 columns:
+//
+//   k_update_diag  (k-1 -> k)   the 256 x 256 DIAGONAL block of block k receives block k-1's
+//                               update first (10 tiles, one 16-wavefront workgroup each)
+//   k_diag_chain   D(k)         ONE workgroup of 16 wavefronts factorises that diagonal block:
+//                               four 64-column sub-panels; per sub-panel the 64 x 64 tile is
+//                               eliminated by wavefront 0 (lane <-> row, v_readlane broadcasts),
+//                               the block's rows below ride one 16-column step behind on
+//                               wavefronts 1-3, MFMA updates on all 16; then the inverses of
+//                               the four unit-lower diagonal tiles (the solves and k_trsm_block
+//                               multiply with them).  This is the factorisation's critical
+//                               chain of N sequential pivots -- and nothing else is.
+//   k_ldlt_update  U(k-1)       the rest of block k-1's trailing update, launched ANY-ORDER
+//                               right behind D(k): it does not wait for D(k), the two run side
+//                               by side (they touch disjoint cache lines), and the next ordinary
+//                               launch waits for both.  Look-ahead inside one queue.
+//   k_trsm_block   T(k)         all rows below the block: X = T inv(L_kk)^T blocked by 64
+//                               (MFMA, the tile inverses from D(k)); writes W = X = L D (the
+//                               operand of U(k)) and L = X D^-1.
+//
+// The round-1 schedule ran 80 panel launches of 22-33 us one after the other with the bulk
+// updates between them (2.3 ms of 4.0 ms per step at N = 5120); here the serial part is
+// D(k) (~60 us per 256 columns) and for the large early blocks it hides behind U(k-1).
+#include <hip/hip_ext.h>
+
+#include "pgf_internal.h"
+#include "pgf_ldlt_dev.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+#define C_LD 66    // LDS row stride of 64-column tiles: conflict-free MFMA fragment reads
+#define C_WLD 18
+#define CH_ROWS 256
+// M[256][66] | Wt[64][18] | D[64] | 1/D[64] | flag
+#define CH_SMEM (CH_ROWS * C_LD * 8 + 64 * C_WLD * 8 + 2 * 64 * 8 + 16)
+
+// ------------------------------------------------------------------ TS x TS tile product
+// One 16 x 16 MFMA tile per wavefront of a (TS / 16)^2-wavefront workgroup:
+//   acc -= sum_{k < kd} A[i0 + i][k] * B[j0 + j][k]
+// A and B are row-major in global memory (k contiguous, first column already applied to the
+// pointers), staged through LDS in 64-deep chunks with the next chunk's loads in flight behind
+// the current chunk's MFMAs.  v_mfma_f64_16x16x4_f64 operand layout: A: lane l holds
+// A[l & 15][l >> 4], B: B[l >> 4][l & 15], C/D: row (l >> 4) + 4 reg, col l & 15.
+template <int TS>
+__device__ __forceinline__ void tile_msub(double4_t &acc, double (*As)[C_LD], double (*Bs)[C_LD],
+                                          const double *A, int64_t lda, int i0, int ilim,
+                                          const double *B, int64_t ldb, int j0, int jlim, int kd) {
+  constexpr int WPR = TS / 16, NT = 64 * WPR * WPR, NQ = TS * 32 / NT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WPR, wc = wave % WPR, l15 = lane & 15, l4 = lane >> 4;
+  double2_t va[NQ], vb[NQ];
+  auto fetch = [&](int kk) {  // chunk [kk, kk + 64) -> registers
+    const int kc = min(64, kd - kk);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int p = q * NT + tid;
+      const int row = p >> 5, c2 = (p & 31) * 2;
+      double2_t a = (double2_t){0.0, 0.0}, b = (double2_t){0.0, 0.0};
+      if (i0 + row < ilim) {
+        const double *src = A + (int64_t)(i0 + row) * lda + kk + c2;
+        if (c2 + 1 < kc) a = *reinterpret_cast<const double2_t *>(src);
+        else if (c2 < kc) a.x = *src;
+      }
+      if (j0 + row < jlim) {
+        const double *src = B + (int64_t)(j0 + row) * ldb + kk + c2;
+        if (c2 + 1 < kc) b = *reinterpret_cast<const double2_t *>(src);
+        else if (c2 < kc) b.x = *src;
+      }
+      va[q] = a;
+      vb[q] = b;
+    }
+  };
+  if (kd > 0) fetch(0);
+  for (int kk = 0; kk < kd; kk += 64) {
+    const int kc = min(64, kd - kk);
+    __syncthreads();  // the previous chunk's fragment reads are done
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int p = q * NT + tid;
+      const int row = p >> 5, c2 = (p & 31) * 2;
+      *reinterpret_cast<double2_t *>(&As[row][c2]) = -va[q];
+      *reinterpret_cast<double2_t *>(&Bs[row][c2]) = vb[q];
+    }
+    __syncthreads();
+    if (kk + 64 < kd) fetch(kk + 64);  // in flight during this chunk's MFMAs
+    const int kr = (kc + 3) & ~3;
+#pragma unroll 4
+    for (int ks = 0; ks < kr; ks += 4) {
+      const double a = As[16 * wr + l15][ks + l4];
+      const double b = Bs[16 * wc + l15][ks + l4];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ U_diag
+// Diagonal block of the NEXT outer block (rows / columns [c1, c1 + nb1)) -= W L^T of the
+// current one (K-depth kd, L in columns [kc0, kc0 + kd) of K, W block-relative).  One
+// workgroup per TS x TS tile of the lower triangle; TS = 32: 36 workgroups of 4 wavefronts
+// (a tile is 2 TS^2 kd flops on ONE CU's matrix pipes: 6.8 us at TS = 64, 1.7 us at 32).
+template <int TS>
+__global__ __launch_bounds__(4 * TS * TS / 16) void k_update_diag(double *K, int64_t ldk,
+                                                                  const double *W, int64_t ldw,
+                                                                  int kc0, int kd, int c1, int nb1) {
+  constexpr int WPR = TS / 16;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TS * C_LD * 8];
+  double(*As)[C_LD] = reinterpret_cast<double(*)[C_LD]>(smem);
+  double(*Bs)[C_LD] = reinterpret_cast<double(*)[C_LD]>(smem + TS * C_LD * 8);
+  int I = 0, t = blockIdx.x;
+  while (t > I) {
+    t -= I + 1;
+    ++I;
+  }
+  const int J = t;  // J <= I
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave / WPR, wc = wave % WPR, l15 = lane & 15, l4 = lane >> 4;
+  const int lim = c1 + nb1;
+  const int i0 = c1 + TS * I, j0 = c1 + TS * J;
+  double4_t acc;
+  const int j = j0 + 16 * wc + l15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = i0 + 16 * wr + l4 + 4 * r;
+    acc[r] = (i < lim && j < lim && j <= i) ? K[(int64_t)i * ldk + j] : 0.0;
+  }
+  tile_msub<TS>(acc, As, Bs, W, ldw, i0, lim, K + kc0, ldk, j0, lim, kd);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = i0 + 16 * wr + l4 + 4 * r;
+    if (i < lim && j < lim && j <= i) K[(int64_t)i * ldk + j] = acc[r];
+  }
+}
+
+// ------------------------------------------------------------------ T(k)
+// Rows below outer block [c0, c0 + nb): workgroup g owns rows r0 = c0 + nb + 64 g ... + 63
+// (row N, a carried right-hand side, included).  Per 64-column sub-panel s, left-looking:
+//   T_s = K[rows, sub-panel s] - sum_{t < s} X_t L_st^T ;  X_s = T_s inv(L_ss)^T
+//   W[rows, 64 s ..] = X_s (= L D) ;  K[rows, sub-panel s] = X_s D^-1 (= L)
+// The workgroup's whole 64 x 256 strip starts in registers (one 16 x 16 accumulator per
+// wavefront and sub-panel), the X_t it produces stay in LDS as the A operands of the later
+// sub-panels, and the ten B tiles (L_10, inv_1, L_20, L_21, inv_2, ...) stream from the
+// L2-resident diagonal block through ONE LDS buffer with the next tile's loads in flight
+// behind the current tile's MFMAs.
+// RT rows per workgroup (4 wavefronts per 16 rows).  The MFMA work of a workgroup is RT x 256
+// x 256 flops on ONE CU's matrix pipes (0.3 TFLOP/s): 17 us at RT = 64, so RT = 16 and four
+// times as many workgroups (the B tiles come from L2 either way).
+template <int RT>
+__global__ __launch_bounds__(RT * 16) void k_trsm_block(double *K, int64_t ldk, double *W,
+                                                     int64_t ldw, int nrows, int c0, int nb,
+                                                     const double *__restrict__ dinv,
+                                                     const double *__restrict__ Linv) {
+  constexpr int NT = RT * 16;          // threads
+  constexpr int NQ = 2048 / NT;        // 16-byte pieces of a 64 x 64 B tile per thread
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(3 * RT + 64) * C_LD * 8 + 256 * 8];
+  double(*Bs)[C_LD] = reinterpret_cast<double(*)[C_LD]>(smem + 3 * RT * C_LD * 8);
+  double *ds = reinterpret_cast<double *>(smem + (3 * RT + 64) * C_LD * 8);
+  auto Xs = [&](int t) { return reinterpret_cast<double(*)[C_LD]>(smem + (size_t)t * RT * C_LD * 8); };
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3, l15 = lane & 15, l4 = lane >> 4;
+  const int bend = c0 + nb;
+  const int r0 = bend + RT * (int)blockIdx.x;
+  const int ns = (nb + 63) / 64;
+  // B tile of step (s, t): t < s: rows of sub-panel s of the factored diagonal block, columns
+  // of sub-panel t (L_st); t == s: the inverse of diagonal tile s
+  double2_t pb[NQ];
+  auto fetch_b = [&](int s_, int t_) {
+    const int cb = c0 + 64 * s_;
+    const int ncol = min(64, bend - cb);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int p = q * NT + tid;
+      const int row = p >> 5, c2 = (p & 31) * 2;
+      double2_t b = (double2_t){0.0, 0.0};
+      if (t_ == s_)
+        b = *reinterpret_cast<const double2_t *>(Linv + (size_t)(cb / 64) * 4096 + row * 64 + c2);
+      else if (row < ncol)
+        b = *reinterpret_cast<const double2_t *>(K + (int64_t)(cb + row) * ldk + c0 + 64 * t_ + c2);
+      pb[q] = b;
+    }
+  };
+  fetch_b(0, 0);
+  double4_t acc[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int cb = c0 + 64 * s;
+    const int j = cb + 16 * wc + l15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = r0 + 16 * wr + l4 + 4 * r;
+      acc[s][r] = (i < nrows && j < bend) ? K[(int64_t)i * ldk + j] : 0.0;
+    }
+  }
+  for (int i = tid; i < 256; i += NT) ds[i] = (i < nb) ? dinv[c0 + i] : 0.0;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (s < ns) {
+      const int cb = c0 + 64 * s;
+      const int ncol = min(64, bend - cb);
+#pragma unroll
+      for (int t = 0; t <= s; ++t) {
+        __syncthreads();  // Bs free; the X tiles written so far are visible
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int p = q * NT + tid;
+          *reinterpret_cast<double2_t *>(&Bs[p >> 5][(p & 31) * 2]) = pb[q];
+        }
+        double(*St)[C_LD] = Xs(s < 3 ? s : 0);  // staging tile of the solve (s == 3: X_0 is dead)
+        if (t == s) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) St[16 * wr + l4 + 4 * r][16 * wc + l15] = acc[s][r];
+        }
+        __syncthreads();
+        // next B tile: (s, t + 1) or (s + 1, 0)
+        if (t < s) fetch_b(s, t + 1);
+        else if (s + 1 < ns) fetch_b(s + 1, 0);
+        if (t < s) {
+          double(*Xa)[C_LD] = Xs(t);
+          double4_t a4 = acc[s];
+#pragma unroll 4
+          for (int ks = 0; ks < 64; ks += 4) {
+            const double a = -Xa[16 * wr + l15][ks + l4];
+            const double b = Bs[16 * wc + l15][ks + l4];
+            a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, a4, 0, 0, 0);
+          }
+          acc[s] = a4;
+        } else {
+          // X[i][j] = sum_k T[i][k] inv[j][k]
+          double4_t x = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+          for (int ks = 0; ks < 64; ks += 4) {
+            const double a = St[16 * wr + l15][ks + l4];
+            const double b = Bs[16 * wc + l15][ks + l4];
+            x = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, x, 0, 0, 0);
+          }
+          __syncthreads();  // all reads of T done: X replaces it
+#pragma unroll
+          for (int r = 0; r < 4; ++r) St[16 * wr + l4 + 4 * r][16 * wc + l15] = x[r];
+          __syncthreads();
+          for (int p = tid; p < RT * 32; p += NT) {
+            const int row = p >> 5, c2 = (p & 31) * 2;
+            const int r = r0 + row;
+            if (r >= nrows || c2 >= ncol) continue;
+            const double2_t w = *reinterpret_cast<const double2_t *>(&St[row][c2]);
+            double2_t l;
+            l.x = w.x * ds[64 * s + c2];
+            l.y = w.y * ds[64 * s + c2 + 1];
+            double *wp = W + (int64_t)r * ldw + 64 * s + c2;
+            double *kp = K + (int64_t)r * ldk + cb + c2;
+            if (c2 + 1 < ncol) {
+              *reinterpret_cast<double2_t *>(wp) = w;
+              *reinterpret_cast<double2_t *>(kp) = l;
+            } else {
+              wp[0] = w.x;
+              kp[0] = l.x;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ D(k)
+// wavefront 0: right-looking elimination of the 16 columns of sub-block sb of the 64 x 64
+// diagonal tile, lane <-> row (the scheme of panel_body's (a+), pgf_ldlt.hip): the tile's rows
+// and, in the same instruction stream, the tile rows below it; emits L into M, W = L D of the
+// rows below the 16 x 16 tile into Wt, D and 1/D.
+__device__ __forceinline__ void chain_a_plus(double (*M)[C_LD], double (*Wt)[C_WLD], double *dD,
+                                             double *dI, int &s_bad, int lane, int sb, int ncol) {
+  const int cb = sb * 16;
+  double a[16], w[16];
+#pragma unroll
+  for (int k = 0; k < 16; k += 2) {
+    const double2_t v = *reinterpret_cast<const double2_t *>(&M[lane][cb + k]);
+    a[k] = v.x;
+    a[k + 1] = v.y;
+  }
+  // The serial chain of the whole factorisation runs through this loop: pivot -> reciprocal ->
+  // multiplier column -> the ONE entry the next pivot needs -> next pivot.  Written software-
+  // pipelined, with a scheduling barrier per column: left alone, the compiler's list scheduler
+  // turns the right-looking updates into a lazy (left-looking) order in which column j waits
+  // for a chain of j dependent FMAs right before its pivot -- 3.5 us per 16 columns instead
+  // of about one.  Per column: the next pivot's entry is updated first and its reciprocal
+  // chain started, the other 14 - j updates (independent FMAs, two v_readlane each) fill in.
+  // classes flagged bad: sNaN, qNaN, -inf, -0, +0, +inf
+  // Dependent fp64 operations cost ~30 cycles each on a lone wavefront, so the chain carries
+  // as few as possible: reciprocal seed + ONE Newton step (v_rcp_f64 delivers > 26 bits; the
+  // pivots only enter through products and the 1e-10 bar leaves five digits), and the product
+  // of the next pivot's two factors is formed while the reciprocal is still in flight:
+  //   a[j+1] -= (w[j] * c) * (1 / d)   instead of   a[j+1] -= (w[j] / d) * c.
+  double d = lane_bcast(a[0], cb);
+  bool bad_any = __builtin_amdgcn_class(d, 0x1 | 0x2 | 0x4 | 0x20 | 0x40 | 0x200) && cb < ncol;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    w[j] = a[j];
+    double r = __builtin_amdgcn_rcp(d);
+    double pc = 0.0;
+    if (j + 1 < 16) pc = a[j] * lane_bcast(a[j], cb + j + 1);  // beside the reciprocal
+    r = fma(r, fma(-d, r, 1.0), r);
+    if (j + 1 < 16) {
+      a[j + 1] = fma(-pc, r, a[j + 1]);
+      d = lane_bcast(a[j + 1], cb + j + 1);
+      bad_any |= __builtin_amdgcn_class(d, 0x1 | 0x2 | 0x4 | 0x20 | 0x40 | 0x200) &&
+                 (cb + j + 1) < ncol;
+    }
+    const double l = a[j] * r;
+#pragma unroll
+    for (int k = j + 2; k < 16; ++k) a[k] = fma(-l, lane_bcast(w[j], cb + k), a[k]);
+    a[j] = l;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const int tr = lane - cb;  // row inside the 16 x 16 tile
+  if (tr >= 0 && tr < 16) {
+    double d_mine = 1.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (k < tr) M[lane][cb + k] = a[k];
+      if (k == tr) d_mine = w[k];
+    }
+    const bool ok = !__builtin_amdgcn_class(d_mine, 0x1 | 0x2 | 0x4 | 0x20 | 0x40 | 0x200);
+    M[lane][lane] = d_mine;
+    dD[lane] = d_mine;
+    dI[lane] = ok ? fast_recip(d_mine) : 0.0;
+    if (tr == 0 && bad_any) s_bad = 1;
+  } else if (tr >= 16) {
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+      double2_t wv, lv;
+      wv.x = w[k];
+      wv.y = w[k + 1];
+      lv.x = a[k];
+      lv.y = a[k + 1];
+      *reinterpret_cast<double2_t *>(&Wt[lane][k]) = wv;
+      *reinterpret_cast<double2_t *>(&M[lane][cb + k]) = lv;
+    }
+  }
+}
+
+// one lane per stack row below the diagonal tile: x L_bb^T = a_row for sub-block sbp; X (= L D)
+// replaces the row's entries in place.  L_bb: lane j & 15 loads ROW j of the factored tile once
+// and the multipliers are broadcast with v_readlane (scalar operands) -- reading the 120
+// entries as LDS broadcasts lets the scheduler hoist all of them into vector registers at once,
+// which does not fit the 128 registers a lane has in a 16-wavefront workgroup.
+__device__ __forceinline__ void chain_b_own(double (*M)[C_LD], int row, int sbp, int lane) {
+  const int cb = sbp * 16;
+  double x[16], tl[16];
+#pragma unroll
+  for (int k = 0; k < 16; k += 2) {
+    const double2_t v = *reinterpret_cast<const double2_t *>(&M[row][cb + k]);
+    x[k] = v.x;
+    x[k + 1] = v.y;
+    const double2_t u = *reinterpret_cast<const double2_t *>(&M[cb + (lane & 15)][cb + k]);
+    tl[k] = u.x;
+    tl[k + 1] = u.y;
+  }
+#pragma unroll
+  for (int t = 0; t < 15; ++t) {
+    const double xt = x[t];
+#pragma unroll
+    for (int j = t + 1; j < 16; ++j) x[j] = fma(-xt, lane_bcast(tl[t], j), x[j]);  // L_bb[j][t]
+    __builtin_amdgcn_sched_barrier(0);  // eager (right-looking) order, see chain_a_plus
+  }
+#pragma unroll
+  for (int k = 0; k < 16; k += 2) {
+    double2_t wv;
+    wv.x = x[k];
+    wv.y = x[k + 1];
+    *reinterpret_cast<double2_t *>(&M[row][cb + k]) = wv;
+  }
+}
+
+// C (16 x 16 at M[ci][cj]) -= A B^T over 16 k: A rows at (ar, ak) of Am (stride lda doubles),
+// B rows at M[br][bk]
+template <int LDA>
+__device__ __forceinline__ void chain_tile16(double (*M)[C_LD], int ci, int cj,
+                                             const double (*Am)[LDA], int ar, int ak, int br,
+                                             int bk, int l15, int l4) {
+  double4_t acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = M[ci + l4 + 4 * r][cj + l15];
+#pragma unroll
+  for (int ks = 0; ks < 16; ks += 4) {
+    const double av = -Am[ar + l15][ak + ks + l4];
+    const double bv = M[br + l15][bk + ks + l4];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) M[ci + l4 + 4 * r][cj + l15] = acc[r];
+}
+
+// block column Q of the inverse of a unit-lower 64 x 64 tile whose diagonal 16 x 16 sub-tiles
+// already hold their inverses (see the end of k_diag_chain); one wavefront.  Xo[p - Q - 1] =
+// block (p, Q), p > Q, in MFMA C layout.
+template <int Q>
+__device__ __forceinline__ void inv_block_column(const double (*Lg)[C_LD], double4_t (&Xo)[3],
+                                                 int l15, int l4) {
+  double4_t X[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) X[Q][rr] = Lg[16 * Q + 4 * rr + l4][16 * Q + l15];
+#pragma unroll
+  for (int p = Q + 1; p < 4; ++p) {
+    double4_t S = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = Q; r < p; ++r)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        S = __builtin_amdgcn_mfma_f64_16x16x4f64(Lg[16 * p + l15][16 * r + 4 * rr + l4], X[r][rr], S,
+                                                 0, 0, 0);
+    double4_t Xp = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+      Xp = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lg[16 * p + l15][16 * p + 4 * rr + l4], S[rr], Xp, 0,
+                                                0, 0);
+    X[p] = Xp;
+    Xo[p - Q - 1] = Xp;
+  }
+}
+
+template <int NW>
+__device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64_t ldk, int c0,
+                                           int nb, double *__restrict__ dvec,
+                                           double *__restrict__ dinv, int *__restrict__ flags,
+                                           double *__restrict__ Linv, double *__restrict__ LinvT,
+                                           long long *__restrict__ dbg) {
+  double(*M)[C_LD] = reinterpret_cast<double(*)[C_LD]>(smem);
+  double(*Wt)[C_WLD] = reinterpret_cast<double(*)[C_WLD]>(smem + CH_ROWS * C_LD * 8);
+  double *dD = reinterpret_cast<double *>(smem + CH_ROWS * C_LD * 8 + 64 * C_WLD * 8);
+  double *dI = dD + 64;
+  int &s_bad = *reinterpret_cast<int *>(dI + 64);
+  constexpr int NT = 64 * NW;  // NW = 16 or 8 wavefronts (8: 256 registers per lane)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int bend = c0 + nb;
+  const int ns = (nb + 63) / 64;
+  // PGF_CHAIN_TIMING: phase stamps of the first sub-panel (100 MHz wall clock), thread 0
+  int dbi = 0;
+#define CH_STAMP()                                               \
+  do {                                                           \
+    if (dbg && tid == 0 && dbi < 32) dbg[dbi++] = wall_clock64(); \
+  } while (0)
+  CH_STAMP();
+
+  for (int s = 0; s < ns; ++s) {
+    const int cb = c0 + 64 * s;
+    const int ncol = min(64, bend - cb);
+    const int own = max(0, bend - cb - 64);  // block rows below the tile (ncol == 64 if any)
+    const int ownp = (own + 63) & ~63;       // padded to whole wavefronts of rows
+    if (tid == 0) s_bad = 0;
+    // ---- load the stack: diagonal tile (identity outside the valid lower triangle) + the
+    // block's rows below, all loads of a lane in flight before its first LDS store
+    {
+      constexpr int NQ = 8192 / NT;
+      double2_t v[NQ];
+      const int np = (64 + ownp) * 32;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int p = q * NT + tid;
+        const int row = p >> 5, c2 = (p & 31) * 2;
+        double2_t t = (double2_t){0.0, 0.0};
+        if (p < np) {
+          if (row < 64) {
+            if (row < ncol) {
+              const double *src = K + (int64_t)(cb + row) * ldk + cb + c2;
+              if (c2 + 1 <= row) t = *reinterpret_cast<const double2_t *>(src);
+              else if (c2 <= row) t.x = *src;
+            } else {
+              if (c2 == row) t.x = 1.0;
+              if (c2 + 1 == row) t.y = 1.0;
+            }
+          } else if (row < 64 + own) {
+            t = *reinterpret_cast<const double2_t *>(K + (int64_t)(cb + row) * ldk + cb + c2);
+          }
+        }
+        v[q] = t;
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int p = q * NT + tid;
+        if (p < np) *reinterpret_cast<double2_t *>(&M[p >> 5][(p & 31) * 2]) = v[q];
+      }
+    }
+    __syncthreads();
+    CH_STAMP();  // stack loaded
+
+    // ---- 64-column panel, four 16-column steps.  Critical path = wavefront 0; the rows below
+    // the tile follow one step behind on wavefronts 1..3 (64 rows each); MFMA updates on all.
+    const int ot = ownp / 16;  // 16-row tiles below the diagonal tile
+    for (int sb = 0; sb < 4; ++sb) {
+      if (wave == 0) chain_a_plus(M, Wt, dD, dI, s_bad, lane, sb, ncol);
+      else if (wave <= 3 && sb > 0 && 64 * (wave - 1) < own) chain_b_own(M, 64 * wave + lane, sb - 1, lane);
+      __syncthreads();
+      if (s == 0) CH_STAMP();  // phase 1 of step sb
+      // diagonal tile: (ti, tj), tj in (sb, 3], ti in [tj, 3], step sb;
+      // rows below:    (ti, tj), tj in [sb, 3], ti in [4, 4 + ot), step sb - 1
+      const int nd = (3 - sb) * (4 - sb) / 2;
+      const int no = sb > 0 ? ot * (4 - sb) : 0;
+      for (int e0 = wave; e0 < nd + no; e0 += NW) {
+        if (e0 < nd) {
+          int e = e0, tj = sb + 1;
+          while (e >= 4 - tj) {
+            e -= 4 - tj;
+            ++tj;
+          }
+          const int ti = tj + e;
+          chain_tile16<C_WLD>(M, ti * 16, tj * 16, Wt, ti * 16, 0, tj * 16, sb * 16, l15, l4);
+        } else {
+          const int e = e0 - nd;
+          const int tj = sb + e / ot, ti = 4 + e % ot;
+          chain_tile16<C_LD>(M, ti * 16, tj * 16, M, ti * 16, (sb - 1) * 16, tj * 16, (sb - 1) * 16,
+                             l15, l4);
+        }
+      }
+      __syncthreads();
+    }
+    if (s == 0) CH_STAMP();  // four steps done
+    if (wave >= 1 && wave <= 3 && 64 * (wave - 1) < own) chain_b_own(M, 64 * wave + lane, 3, lane);
+    __syncthreads();
+    CH_STAMP();  // panel factored
+
+    // ---- trailing update inside the block (rows / columns below the tile, K-depth 64, A = -X
+    // from M, B = X D^-1): the C tiles live in global memory; ALL of a wavefront's tiles are
+    // fetched in one burst here, so that their latency (they were last written by another
+    // kernel: HBM / Infinity Cache, ~2 us) is paid once and hides behind the write-back.
+    constexpr int MT = 96 / NW;  // 16 x 16 MFMA tiles per wavefront (6 tiles of 64 x 64 at most)
+    const int nt = ownp / 64;
+    const int total = nt * (nt + 1) / 2 * 16;
+    auto decode = [&](int e, int &gi, int &gj, int &mi, int &mj) {
+      int T = e >> 4, I = 0;
+      while (T > I) {
+        T -= I + 1;
+        ++I;
+      }
+      const int ti = (e >> 2) & 3, tj = e & 3;
+      mi = 64 + 64 * I + 16 * ti;
+      mj = 64 + 64 * T + 16 * tj;
+      gi = cb + mi;
+      gj = cb + mj;
+    };
+    double4_t ct[MT];
+#pragma unroll
+    for (int q = 0; q < MT; ++q) {
+      const int e = wave + q * NW;
+      ct[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      if (e < total) {
+        int gi, gj, mi, mj;
+        decode(e, gi, gj, mi, mj);
+        const int j = gj + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = gi + l4 + 4 * r;
+          if (i < bend && j < bend && j <= i) ct[q][r] = K[(int64_t)i * ldk + j];
+        }
+      }
+    }
+    // ---- write back: factored tile, D, 1/D, flags; rows below: L = X D^-1
+    for (int p = tid; p < 64 * 64; p += NT) {
+      const int row = p >> 6, c = p & 63;
+      if (row < ncol && c <= row) K[(int64_t)(cb + row) * ldk + cb + c] = M[row][c];
+    }
+    if (tid < ncol) {
+      dvec[cb + tid] = dD[tid];
+      dinv[cb + tid] = dI[tid];
+    }
+    if (wave == 0) {
+      const unsigned long long negs = __ballot(lane < ncol && dD[lane] < 0.0);
+      if (lane == 0) {
+        if (s_bad) atomicOr(&flags[0], 1);
+        const int neg = __popcll(negs);
+        if (neg) atomicAdd(&flags[1], neg);
+      }
+    }
+    for (int p = tid; p < own * 32; p += NT) {
+      const int row = 64 + (p >> 5), c2 = (p & 31) * 2;
+      double2_t v = *reinterpret_cast<const double2_t *>(&M[row][c2]);
+      v.x *= dI[c2];
+      v.y *= dI[c2 + 1];
+      *reinterpret_cast<double2_t *>(K + (int64_t)(cb + row) * ldk + cb + c2) = v;
+    }
+    if (s == 0) CH_STAMP();  // written back
+#pragma unroll
+    for (int q = 0; q < MT; ++q) {
+      const int e = wave + q * NW;
+      if (e < total) {
+        int gi, gj, mi, mj;
+        decode(e, gi, gj, mi, mj);
+        if (gj <= gi + 15) {  // not entirely above the diagonal
+          double4_t c = ct[q];
+#pragma unroll 4
+          for (int ks = 0; ks < 64; ks += 4) {
+            const double av = -M[mi + l15][ks + l4];
+            const double bv = M[mj + l15][ks + l4] * dI[ks + l4];
+            c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
+          }
+          const int j = gj + l15;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = gi + l4 + 4 * r;
+            if (i < bend && j < bend && j <= i) K[(int64_t)i * ldk + j] = c[r];
+          }
+        }
+      }
+    }
+    __syncthreads();  // M is reloaded next; the global tiles written above are read back
+    CH_STAMP();  // in-block update done
+  }
+
+  // ---- inverses of the block's unit-lower diagonal tiles, four wavefronts per tile, blocked by
+  // 16: wavefront v inverts the 16 x 16 diagonal sub-tile v by substitution (lane c <-> column
+  // c), then wavefront q < 3 builds block column q of the inverse top down,
+  //   X_pq = -D_p sum_{r = q}^{p-1} L_pr X_rq   (D_p = inv(L_pp), X_qq = D_q),
+  // with MFMA: a 16 x 16 accumulator (row (l >> 4) + 4 reg, column l & 15) IS the B operand
+  // of the next four k-steps, so the X_rq stay in registers.  Stored as inv and as its
+  // transpose, [tile][row][64]: forward and backward solves both read coalesced rows.
+  for (int g0 = 0; g0 < ns; g0 += NW / 4) {
+    const int g = g0 + (wave >> 2), v = wave & 3;
+    double(*Lg)[C_LD] = reinterpret_cast<double(*)[C_LD]>(smem + (size_t)(wave >> 2) * 64 * C_LD * 8);
+    const int b0 = c0 + 64 * g;
+    const int nbw = min(64, bend - b0);
+    const bool live = g < ns;
+    if (live) {
+      for (int idx = tid & 255; idx < 64 * 32; idx += 256) {
+        const int row = idx >> 5, c2 = (idx & 31) * 2;
+        double2_t t = (double2_t){0.0, 0.0};
+        if (row < nbw) {
+          const double *src = K + (int64_t)(b0 + row) * ldk + b0 + c2;
+          if (c2 + 1 < row) t = *reinterpret_cast<const double2_t *>(src);
+          else if (c2 < row) t.x = *src;
+        }
+        if (c2 == row) t.x = 1.0;
+        if (c2 + 1 == row) t.y = 1.0;
+        *reinterpret_cast<double2_t *>(&Lg[row][c2]) = t;
+      }
+    }
+    __syncthreads();
+    if (live && lane < 16) {
+      double y[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) y[j] = (j == lane) ? 1.0 : 0.0;
+#pragma unroll
+      for (int t = 0; t < 15; ++t) {
+        const double yt = y[t];
+#pragma unroll
+        for (int j = t + 1; j < 16; ++j) y[j] = fma(-yt, Lg[16 * v + j][16 * v + t], y[j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) Lg[16 * v + j][16 * v + lane] = y[j];
+    }
+    __syncthreads();
+    double4_t Xo[3];
+    if (live) {
+      if (v == 0) inv_block_column<0>(Lg, Xo, l15, l4);
+      else if (v == 1) inv_block_column<1>(Lg, Xo, l15, l4);
+      else if (v == 2) inv_block_column<2>(Lg, Xo, l15, l4);
+    }
+    __syncthreads();  // every wavefront is done reading the L blocks: the X blocks go in place
+    if (live && v < 3) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int pb = v + 1 + t;
+        if (pb < 4) {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) Lg[16 * pb + l4 + 4 * rr][16 * v + l15] = Xo[t][rr];
+        }
+      }
+    }
+    __syncthreads();
+    if (live) {
+      double *o = Linv + (size_t)(b0 / 64) * 4096;
+      double *ot = LinvT + (size_t)(b0 / 64) * 4096;
+      for (int idx = tid & 255; idx < 64 * 64; idx += 256) {
+        const int row = idx >> 6, col = idx & 63;
+        o[idx] = Lg[row][col];
+        ot[idx] = Lg[col][row];
+      }
+    }
+    __syncthreads();  // Lg is refilled by the next pass
+  }
+  CH_STAMP();  // inverses done
+#undef CH_STAMP
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_diag_chain(double *K, int64_t ldk, int c0, int nb,
+                                                     double *__restrict__ dvec,
+                                                     double *__restrict__ dinv,
+                                                     int *__restrict__ flags,
+                                                     double *__restrict__ Linv,
+                                                     double *__restrict__ LinvT,
+                                                     long long *__restrict__ dbg) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[CH_SMEM];
+  chain_body<NW>(smem, K, ldk, c0, nb, dvec, dinv, flags, Linv, LinvT, dbg);
+}
+
+// ------------------------------------------------------------------ D(k + 1) beside U(k)
+// ONE launch: workgroup 0 is the chain D(k + 1) of the next outer block; every other workgroup
+// updates four 64 x 64 tiles of block k's trailing update U(k) below the next diagonal block
+// (rows [row0, nrows) x columns [col0, colEnd), lower triangle; update_tile of the
+// k_ldlt_update kernel, one tile per group of four wavefronts, each group with its own LDS
+// slice).  The two roles touch disjoint cache lines and hand nothing to each other, so the
+// launch is correct whatever order the workgroups run in; dispatched first, the chain has its
+// CU to itself (its LDS footprint keeps other workgroups off) and runs in the shadow of the
+// update -- look-ahead without a second queue (which broke results in round 1) and without
+// hipExtAnyOrderLaunch (which on this stack starts the kernel early but not concurrently).
+__global__ __launch_bounds__(1024) void k_chain_update(double *K, int64_t ldk, int c0, int nb,
+                                                       double *__restrict__ dvec,
+                                                       double *__restrict__ dinv,
+                                                       int *__restrict__ flags,
+                                                       double *__restrict__ Linv,
+                                                       double *__restrict__ LinvT,
+                                                       long long *__restrict__ dbg,
+                                                       const double *W, int64_t ldw, int N,
+                                                       int nrows, int row0, int col0, int colEnd,
+                                                       int kc0, int KB) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[CH_SMEM];
+  if (blockIdx.x == 0) {
+    chain_body<16>(smem, K, ldk, c0, nb, dvec, dinv, flags, Linv, LinvT, dbg);
+    return;
+  }
+  const int sub = threadIdx.x >> 8, ltid = threadIdx.x & 255;
+  // linear tile id -> (tile row by, tile column bx): row by holds the tiles not entirely
+  // above the diagonal
+  int t = ((int)blockIdx.x - 1) * 4 + sub;
+  const int tr = (nrows - row0 + 63) / 64, tc = (colEnd - col0 + 63) / 64;
+  int by = 0;
+  while (by < tr) {
+    const int nc = min(tc, (row0 + 64 * by + 63 - col0) / 64 + 1);
+    if (t < nc) break;
+    t -= nc;
+    ++by;
+  }
+  // a group past the last tile still takes part in the workgroup's barriers: it runs an
+  // all-masked tile (i0 = nrows: nothing is loaded or stored)
+  const int i0 = by < tr ? row0 + 64 * by : nrows;
+  const int j0 = by < tr ? col0 + 64 * t : col0;
+  update_tile<64, 64, 16>(smem + sub * ((64 + 64) * 18 * 8), ltid, i0, j0, K, ldk, W, ldw, N, nrows,
+                          colEnd, kc0, KB);
+}
+
+// ------------------------------------------------------------------ host schedule
+bool ldlt_use_lookahead() {
+  static const bool on = !(getenv("PGF_FACTOR") && atoi(getenv("PGF_FACTOR")) == 1);
+  return on;
+}
+
+// wavefronts of the chain workgroup: 16 (128 registers per lane, a few spilled) or 8
+static int chain_waves() {
+  static const int nw = (getenv("PGF_CHAIN_WAVES") && atoi(getenv("PGF_CHAIN_WAVES")) == 8) ? 8 : 16;
+  return nw;
+}
+
+static bool fused() {
+  static const bool on = !(getenv("PGF_FUSED") && atoi(getenv("PGF_FUSED")) == 0);
+  return on;
+}
+
+// PGF_CHAIN_TIMING=1 (diagnostic): the chain kernel of the FIRST block of every factorisation
+// stamps its phases into this buffer; ldlt_chain_timing_dump prints the last set
+static long long *g_chain_dbg = nullptr;
+static long long *chain_dbg_buffer() {
+  static const bool on = getenv("PGF_CHAIN_TIMING") != nullptr;
+  if (!on) return nullptr;
+  if (!g_chain_dbg) {
+    if (hipMalloc((void **)&g_chain_dbg, 32 * sizeof(long long)) != hipSuccess) return nullptr;
+    (void)hipMemset(g_chain_dbg, 0, 32 * sizeof(long long));
+  }
+  return g_chain_dbg;
+}
+void ldlt_chain_timing_dump() {
+  if (!g_chain_dbg) return;
+  long long h[32];
+  if (hipMemcpy(h, g_chain_dbg, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
+  fprintf(stderr, "k_diag_chain phase stamps (us since kernel start):");
+  for (int i = 1; i < 32 && h[i]; ++i) fprintf(stderr, " %.2f", (double)(h[i] - h[0]) * 0.01);
+  fprintf(stderr, "\n");
+}
+
+hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
+  f.N = N;
+  f.factored = false;
+  hipStream_t s = f.stream;
+  hipError_t e = hipMemsetAsync(f.flags, 0, 4 * sizeof(int), s);
+  if (e != hipSuccess) return e;
+  PgfProfile *p = (f.prof && f.prof->enabled) ? f.prof : nullptr;
+  if (p) {
+    p->factor_spans.emplace_back(prof_event(p), prof_event(p));
+    (void)hipEventRecord(p->factor_spans.back().first, s);
+  }
+  constexpr int OB = 256;
+  const int64_t ldw = OB;
+  auto launch_d = [&](int c0) {
+    long long *dbg = (c0 == 0) ? chain_dbg_buffer() : nullptr;
+    if (chain_waves() == 16)
+      hipLaunchKernelGGL(k_diag_chain<16>, dim3(1), dim3(1024), 0, s, f.K, f.ldk, c0,
+                         std::min(OB, N - c0), f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, dbg);
+    else
+      hipLaunchKernelGGL(k_diag_chain<8>, dim3(1), dim3(512), 0, s, f.K, f.ldk, c0,
+                         std::min(OB, N - c0), f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, dbg);
+  };
+  auto launch_t = [&](int c0, double *Wb) {
+    const int nb = std::min(OB, N - c0);
+    const int below = nrows - (c0 + nb);
+    if (below > 0)
+      hipLaunchKernelGGL(k_trsm_block<16>, dim3((below + 15) / 16), dim3(256), 0, s, f.K, f.ldk, Wb,
+                         ldw, nrows, c0, nb, f.dinv, f.Linv);
+  };
+  int buf = 0;
+  if (N > 0) {
+    launch_d(0);
+    launch_t(0, f.W);
+  }
+  for (int c0 = 0; c0 + OB < N; c0 += OB, buf ^= 1) {
+    const int c1 = c0 + OB, nb1 = std::min(OB, N - c1);
+    const double *Wb = f.W + (size_t)buf * f.wstride;
+    const int nt = (nb1 + 31) / 32;
+    hipLaunchKernelGGL(k_update_diag<32>, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, f.K, f.ldk, Wb,
+                       ldw, c0, OB, c1, nb1);
+    // D(k + 1) and everything of U(k) below the next diagonal block, in one launch; while
+    // profiling (per-kernel events) and on request (PGF_FUSED=0) as two launches
+    const int row0 = c1 + nb1;
+    int ntiles = 0;
+    if (row0 < nrows) {
+      const int tr = (nrows - row0 + 63) / 64, tc = (N - c1 + 63) / 64;
+      for (int by = 0; by < tr; ++by) ntiles += std::min(tc, (row0 + 64 * by + 63 - c1) / 64 + 1);
+    }
+    if (fused() && !p && ntiles > 0) {
+      hipLaunchKernelGGL(k_chain_update, dim3(1 + (ntiles + 3) / 4), dim3(1024), 0, s, f.K, f.ldk, c1,
+                         nb1, f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, (long long *)nullptr, Wb, ldw,
+                         N, nrows, row0, c1, N, c0, OB);
+    } else {
+      launch_d(c1);
+      launch_update(f, s, Wb, ldw, N, nrows, row0, c1, N, c0, OB, p, 0);
+    }
+    launch_t(c1, f.W + (size_t)(buf ^ 1) * f.wstride);
+  }
+  if (p) (void)hipEventRecord(p->factor_spans.back().second, s);
+  e = hipMemcpyAsync(f.h_flags, f.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s);
+  if (e != hipSuccess) return e;
+  return hipGetLastError();
+}

@@ -39,9 +39,6 @@ struct DenseLdlt {
   int chain_stride = 0, chain_epoch = 0;
   int *h_flags = nullptr;   // pinned host mirror ([3]: status word of the chained solves)
   hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;  // look-ahead stream (trailing update)
-  hipEvent_t ev_panel = nullptr, ev_update = nullptr;
-  std::vector<hipEvent_t> ev_ring;  // one event per cross-stream edge of a factorisation
   int OB = 256;             // outer block width (K-depth of the bulk trailing update)
   size_t wstride = 0;       // doubles per W buffer (two buffers)
   int N = 0;
@@ -63,6 +60,14 @@ hipError_t ldlt_solve_async(DenseLdlt &f, const double *rhs, double *sol);
 hipError_t ldlt_backsolve_async(DenseLdlt &f, const double *w, double *sol);
 // after a host sync: nonzero if a chained solve reported a timeout / placement problem
 int ldlt_chain_check(DenseLdlt &f);
+// look-ahead schedule (pgf_factor2.hip): the default; PGF_FACTOR=1 selects the round-1 one
+bool ldlt_use_lookahead();
+hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows);
+void ldlt_chain_timing_dump();  // PGF_CHAIN_TIMING diagnostic
+// shared launch helpers (pgf_ldlt.hip)
+hipEvent_t prof_event(PgfProfile *p);
+void launch_update(DenseLdlt &f, hipStream_t s, const double *Wp, int64_t ldw, int N, int nrows,
+                   int row0, int col0, int colEnd, int kc0, int KB, PgfProfile *p, int any_order);
 
 // ---- batched mode ----------------------------------------------------------
 // One entry per instance of a batch (all instances share n, m): the device addresses of an

@@ -23,64 +23,7 @@
 #include <cmath>
 #include <cstdlib>
 
-typedef double double4_t __attribute__((ext_vector_type(4)));
-typedef double double2_t __attribute__((ext_vector_type(2)));
-
-// ------------------------------------------------------------------ helpers
-// broadcast lane `src` (wave-uniform, compile-time after unrolling) of a double through
-// two v_readlane_b32 (scalar result; no LDS round trip as with __shfl / ds_bpermute)
-__device__ __forceinline__ double lane_bcast(double v, int src) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
-}
-
-// Loads of data another kernel may have written while a second queue was resident (the
-// look-ahead schedule): system-scope relaxed atomic loads (global_load ... sc0 sc1) bypass
-// the per-XCD L2, which is not coherent with the other XCDs' L2s.
-__device__ __forceinline__ double ld_f64(const double *p, int coh) {
-  if (coh) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  return *p;
-}
-__device__ __forceinline__ double2_t ld_f64x2(const double *p, int coh) {
-  double2_t v;
-  if (coh) {
-    v.x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    v.y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  } else {
-    v = *reinterpret_cast<const double2_t *>(p);
-  }
-  return v;
-}
-
-__device__ __forceinline__ void st_f64(double *p, double v, int coh) {
-  if (coh)
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // write-through
-  else
-    *p = v;
-}
-__device__ __forceinline__ void st_f64x2(double *p, double2_t v, int coh) {
-  if (coh) {
-    __hip_atomic_store(p, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(p + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  } else {
-    *reinterpret_cast<double2_t *>(p) = v;
-  }
-}
-
-// 1 / d to within an ulp or two: v_rcp_f64 seed + two Newton steps (5 dependent ops
-// instead of the ~12 of an IEEE-correct division; the pivots only enter through
-// products, which the 1e-10 iterate tolerance covers with 5 digits to spare)
-__device__ __forceinline__ double fast_recip(double d) {
-  double r = __builtin_amdgcn_rcp(d);
-  double e = fma(-d, r, 1.0);
-  r = fma(r, e, r);
-#ifndef PGF_RECIP_ONE_STEP
-  e = fma(-d, r, 1.0);
-  r = fma(r, e, r);
-#endif
-  return r;
-}
+#include "pgf_ldlt_dev.h"
 
 // ------------------------------------------------------------------ fused panel kernel
 // One launch per 64-column panel.  Every workgroup (4 wavefronts) holds in LDS the
@@ -121,7 +64,8 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
   const int l15 = lane & 15, l4 = lane >> 4;
   const int nb = min(NB, N - c0);
   const int rbase = c0 + nb + wg * 64;  // first own row (global)
-  const int coh = (skip >> 3) & 1;      // bit 3 of `skip`: system-scope loads (look-ahead)
+  const int coh = 0;
+  (void)skip;
   if (tid == 0) s_bad = 0;
 
   // ---- load: diag block (identity outside the valid lower triangle) + own rows.
@@ -305,15 +249,15 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
 
   for (int sb = 0; sb < 4; ++sb) {
     // phase 1: (a+) of this step | (b-own) of the previous one | deferred (c-own) tiles
-    if (wave == 0 && !(skip & 1)) a_plus(sb);
-    if (wave == 1 && sb > 0 && !(skip & 2)) b_own(sb - 1);
-    if (wave >= 2 && sb >= 2 && !(skip & 4)) own_deferred(sb);
+    if (wave == 0) a_plus(sb);
+    if (wave == 1 && sb > 0) b_own(sb - 1);
+    if (wave >= 2 && sb >= 2) own_deferred(sb);
     __syncthreads();
     // phase 2: (c-diag) of this step, urgent (c-own) column of the previous one
-    if (!(skip & 4)) phase2(sb);
+    phase2(sb);
     __syncthreads();
   }
-  if (wave == 1 && !(skip & 2)) b_own(3);  // no tiles are left to update after the last step
+  if (wave == 1) b_own(3);  // no tiles are left to update after the last step
   __syncthreads();
 
   // ---- write back: own rows (L), and by workgroup 0 the factored diagonal block
@@ -347,212 +291,6 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
   }
 }
 
-// ------------------------------------------------------------------ trailing update
-// C[i][j] -= sum_k W[i][k] * L[j][k]   for row0 <= i < nrows, col0 <= j < colEnd, j <= i
-// (rows >= N are carried right-hand sides: every column < N is "below" them).
-// 128 x 128 tile per workgroup, 4 wavefronts as 2 x 2, each 64 x 64 = 4 x 4 MFMA tiles
-// of v_mfma_f64_16x16x4_f64 (A: lane l holds A[l&15][l>>4], B: B[l>>4][l&15],
-// C/D: row = (l>>4) + 4*reg, col = l&15).  The accumulators START as the C tile (all 64
-// loads in flight at once, hidden behind the first operand fetch) and -W is staged, so
-// the epilogue is store-only.  K-chunks of 16 go through LDS with the next chunk
-// prefetched into registers; LDS rows padded to 18 doubles (conflict-free ds_read_b64
-// for the fragment pattern, 16-byte aligned ds_write_b128).
-#define UPD_BM 128
-
-// BM x BN = tile (rows x columns); BK = K-chunk staged per barrier pair; 4 wavefronts as
-// 2 x 2, each (BM/2) x (BN/2) = TM x TN MFMA tiles.  LDS rows are padded to BK + 2 doubles.
-template <int BM, int BN, int BK, int WR = 2, int WC = 2, int DB = 0>
-__device__ __forceinline__ void update_tile(unsigned char *smem, const int i0, const int j0,
-                                            double *__restrict__ K, int64_t ldk,
-                                            const double *__restrict__ W, int64_t ldw, int N,
-                                            int nrows, int colEnd, int kc0, int KBc) {
-  const int KB = KBc & 0xFFFFF;        // K-depth
-  const int coh = (KBc >> 20) & 1;     // bit 20: system-scope loads (look-ahead schedule)
-  constexpr int NT = 64 * WR * WC;           // threads per workgroup
-  constexpr int WM = BM / WR, WN = BN / WC;  // rows / columns per wavefront
-  constexpr int TM = WM / 16, TN = WN / 16;  // MFMA tiles per wavefront
-  constexpr int LD = BK + 2;
-  constexpr int PPR = BK / 2;                // 16-byte pieces per row
-  constexpr int PA = BM * PPR / NT, PB = BN * PPR / NT;
-  static_assert(PA >= 1 && PB >= 1, "tile too small for the workgroup");
-  constexpr int STAGE = (BM + BN) * LD * 8;  // bytes of one LDS stage (A then B)
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wr = wave / WC, wc = wave % WC;
-  const int l15 = lane & 15, l4 = lane >> 4;
-
-  // accumulators <- C tile (entries above the diagonal / outside the region are never
-  // stored back; whatever they hold stays confined to its own accumulator element)
-  double4_t acc[TM][TN];
-#pragma unroll
-  for (int mi = 0; mi < TM; ++mi) {
-#pragma unroll
-    for (int nj = 0; nj < TN; ++nj) {
-      const int j = j0 + wc * WN + nj * 16 + l15;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = i0 + wr * WM + mi * 16 + l4 + 4 * r;
-        double v = 0.0;
-        if (i < nrows && j < colEnd && j <= i) v = ld_f64(K + (int64_t)i * ldk + j, coh);
-        acc[mi][nj][r] = v;
-      }
-    }
-  }
-
-  // staging map: piece p = q*256 + tid -> row p / PPR, two doubles at column (p % PPR)*2
-  double2_t pa[PA], pb[PB];
-  auto fetch = [&](int kk, int = 0) {
-#pragma unroll
-    for (int q = 0; q < PA; ++q) {
-      const int p = q * NT + tid;
-      const int row = p / PPR, kofs = (p % PPR) * 2;
-      const int gi = i0 + row;
-      double2_t va = (double2_t){0.0, 0.0};
-      if (gi < nrows) va = ld_f64x2(W + (int64_t)gi * ldw + kk + kofs, coh);
-      pa[q] = va;
-    }
-#pragma unroll
-    for (int q = 0; q < PB; ++q) {
-      const int p = q * NT + tid;
-      const int row = p / PPR, kofs = (p % PPR) * 2;
-      const int gj = j0 + row;
-      double2_t vb = (double2_t){0.0, 0.0};
-      if (gj < colEnd)
-        vb = ld_f64x2(K + (int64_t)gj * ldk + kc0 + kk + kofs, coh);
-      pb[q] = vb;
-    }
-  };
-  auto stage = [&](int buf, int = 0) {
-    double(*As)[LD] = reinterpret_cast<double(*)[LD]>(smem + buf * STAGE);
-    double(*Bs)[LD] = reinterpret_cast<double(*)[LD]>(smem + buf * STAGE + BM * LD * 8);
-    // negate here, not at the fetch: touching the loaded value there would make the
-    // wavefront wait for the prefetch before it starts the current chunk's MFMAs
-#pragma unroll
-    for (int q = 0; q < PA; ++q) {
-      const int p = q * NT + tid;
-      *reinterpret_cast<double2_t *>(&As[p / PPR][(p % PPR) * 2]) = -pa[q];
-    }
-#pragma unroll
-    for (int q = 0; q < PB; ++q) {
-      const int p = q * NT + tid;
-      *reinterpret_cast<double2_t *>(&Bs[p / PPR][(p % PPR) * 2]) = pb[q];
-    }
-  };
-  auto compute = [&](int buf) {
-    double(*As)[LD] = reinterpret_cast<double(*)[LD]>(smem + buf * STAGE);
-    double(*Bs)[LD] = reinterpret_cast<double(*)[LD]>(smem + buf * STAGE + BM * LD * 8);
-#pragma unroll
-    for (int ks = 0; ks < BK; ks += 4) {
-      double a[TM], b[TN];
-#pragma unroll
-      for (int t = 0; t < TM; ++t) a[t] = As[wr * WM + t * 16 + l15][ks + l4];
-#pragma unroll
-      for (int t = 0; t < TN; ++t) b[t] = Bs[wc * WN + t * 16 + l15][ks + l4];
-#pragma unroll
-      for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-        for (int nj = 0; nj < TN; ++nj)
-          acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
-    }
-  };
-
-  fetch(0);
-  if (DB == 2) {
-    // two LDS stages and TWO chunks in flight, in two STATICALLY named register sets (a
-    // runtime-indexed set goes to scratch): the loads of chunk c+2 are issued before chunk c
-    // is computed, so every fetch has two compute phases to land.
-    double2_t qa[PA], qb[PB];  // second register set (the first is pa2[0] / pb2[0])
-    auto fetch1 = [&](int kk) {
-#pragma unroll
-      for (int q = 0; q < PA; ++q) {
-        const int p = q * NT + tid;
-        const int row = p / PPR, kofs = (p % PPR) * 2;
-        const int gi = i0 + row;
-        double2_t va = (double2_t){0.0, 0.0};
-        if (gi < nrows) va = ld_f64x2(W + (int64_t)gi * ldw + kk + kofs, coh);
-        qa[q] = va;
-      }
-#pragma unroll
-      for (int q = 0; q < PB; ++q) {
-        const int p = q * NT + tid;
-        const int row = p / PPR, kofs = (p % PPR) * 2;
-        const int gj = j0 + row;
-        double2_t vb = (double2_t){0.0, 0.0};
-        if (gj < colEnd) vb = ld_f64x2(K + (int64_t)gj * ldk + kc0 + kk + kofs, coh);
-        qb[q] = vb;
-      }
-    };
-    auto stage1 = [&](int buf) {
-      double(*As)[LD] = reinterpret_cast<double(*)[LD]>(smem + buf * STAGE);
-      double(*Bs)[LD] = reinterpret_cast<double(*)[LD]>(smem + buf * STAGE + BM * LD * 8);
-#pragma unroll
-      for (int q = 0; q < PA; ++q) {
-        const int p = q * NT + tid;
-        *reinterpret_cast<double2_t *>(&As[p / PPR][(p % PPR) * 2]) = -qa[q];
-      }
-#pragma unroll
-      for (int q = 0; q < PB; ++q) {
-        const int p = q * NT + tid;
-        *reinterpret_cast<double2_t *>(&Bs[p / PPR][(p % PPR) * 2]) = qb[q];
-      }
-    };
-    const int nc = KB / BK;
-    if (nc > 1) fetch1(BK);
-    stage(0, 0);
-    __syncthreads();
-    for (int c = 0; c < nc; c += 2) {
-      // even chunk c: LDS stage 0; set 1 holds chunk c+1 (in flight); set 0 is free
-      if (c + 2 < nc) fetch((c + 2) * BK, 0);
-      compute(0);
-      if (c + 1 < nc) stage1(1);
-      __syncthreads();
-      if (c + 1 >= nc) break;
-      // odd chunk c+1: LDS stage 1; set 0 holds chunk c+2 (in flight); set 1 is free
-      if (c + 3 < nc) fetch1((c + 3) * BK);
-      compute(1);
-      if (c + 2 < nc) stage(0, 0);
-      __syncthreads();
-    }
-  } else if (DB) {
-    // two LDS stages, ONE barrier per chunk: chunk c is computed from stage c&1 while the
-    // prefetched chunk c+1 is written to the other stage (last read one iteration ago)
-    stage(0);
-    __syncthreads();
-    int cur = 0;
-    for (int kk = 0; kk < KB; kk += BK) {
-      const bool more = kk + BK < KB;
-      if (more) fetch(kk + BK);
-      compute(cur);
-      if (more) stage(cur ^ 1);
-      __syncthreads();
-      cur ^= 1;
-    }
-  } else {
-    for (int kk = 0; kk < KB; kk += BK) {
-      __syncthreads();  // previous chunk's fragment reads are done
-      stage(0);
-      __syncthreads();
-      if (kk + BK < KB) fetch(kk + BK);
-      compute(0);
-    }
-  }
-
-  // epilogue: store-only, lower triangle of the region
-#pragma unroll
-  for (int mi = 0; mi < TM; ++mi) {
-#pragma unroll
-    for (int nj = 0; nj < TN; ++nj) {
-      const int j = j0 + wc * WN + nj * 16 + l15;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = i0 + wr * WM + mi * 16 + l4 + 4 * r;
-        if (i < nrows && j < colEnd && j <= i) st_f64(K + (int64_t)i * ldk + j, acc[mi][nj][r], coh);
-      }
-    }
-  }
-}
-
 template <int BM, int BN, int BK, int WR = 2, int WC = 2, int DB = 0>
 __global__ __launch_bounds__(64 * WR * WC) void k_ldlt_update(
     double *__restrict__ K, int64_t ldk, const double *__restrict__ W, int64_t ldw, int N,
@@ -564,317 +302,8 @@ __global__ __launch_bounds__(64 * WR * WC) void k_ldlt_update(
   const int i0 = row0 + by * BM;
   const int j0 = col0 + bx * BN;
   if (j0 > i0 + BM - 1) return;  // tile entirely above the diagonal
-  update_tile<BM, BN, BK, WR, WC, DB>(smem, i0, j0, K, ldk, W, ldw, N, nrows, colEnd, kc0, KB);
-}
-
-// ------------------------------------------------------------------ 64-bit DPP helpers
-// gfx950 has 64-bit DPP with the row_newbcast control: the source operand is read from lane
-// L of the reader's own 16-lane row.  One v_fmac_f64_dpp therefore does
-//   acc += (value held by lane L of my row) * mult
-// which is exactly the rank-1 update of a 16 x 16 tile whose rows live on the 16 lanes of a
-// row -- no v_readlane pair, no LDS round trip.  hipcc adds no hazard padding inside asm
-// statements, so the two wait states a DPP read needs after a VALU write are in the string.
-template <int L>
-__device__ __forceinline__ void fmac_bcast(double &acc, double from_lane, double mult) {
-  asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-               : "+v"(acc)
-               : "v"(from_lane), "v"(mult), "n"(L));
-}
-template <int L>
-__device__ __forceinline__ double bcast16(double v) {
-  double r;
-  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
-               : "=v"(r)
-               : "v"(v), "n"(L));
-  return r;
-}
-
-// rank-1 update of columns K..15 with pivot column J:  a[K] += A[K][J] * (-l_i)
-template <int J, int K>
-__device__ __forceinline__ void tile_elim(double (&a)[16], double negl) {
-  if constexpr (K < 16) {
-    fmac_bcast<K>(a[K], a[J], negl);
-    tile_elim<J, K + 1>(a, negl);
-  }
-}
-// unblocked LDL^T of the 16 x 16 tile whose row (lane & 15) is in a[0..15]
-template <int J>
-__device__ __forceinline__ void tile_factor(double (&a)[16], int l15, int cb, int nb, double &d_mine,
-                                            double &di_mine, int &bad_any) {
-  if constexpr (J < 16) {
-    const double d = bcast16<J>(a[J]);
-    const bool bad = (d == 0.0) || !(fabs(d) <= 1.79e308);
-    const double di = bad ? 0.0 : fast_recip(d);
-    bad_any |= (bad && (cb + J) < nb) ? 1 : 0;
-    if (l15 == J) {
-      d_mine = d;
-      di_mine = di;
-    }
-    const double l = a[J] * di;
-    tile_elim<J, J + 1>(a, -l);
-    a[J] = l;
-    tile_factor<J + 1>(a, l15, cb, nb, d_mine, di_mine, bad_any);
-  }
-}
-// substitution x L_bb^T = a_row for one row per lane; tl[c] of lane j holds L_bb[j][c]
-template <int T, int J>
-__device__ __forceinline__ void subst_inner(double (&x)[16], const double (&tl)[16], double negxt) {
-  if constexpr (J < 16) {
-    fmac_bcast<J>(x[J], tl[T], negxt);  // x[J] -= x[T] * L_bb[J][T]
-    subst_inner<T, J + 1>(x, tl, negxt);
-  }
-}
-template <int T>
-__device__ __forceinline__ void subst_rows(double (&x)[16], const double (&tl)[16]) {
-  if constexpr (T < 15) {
-    subst_inner<T, T + 1>(x, tl, -x[T]);
-    subst_rows<T + 1>(x, tl);
-  }
-}
-
-// ------------------------------------------------------------------ wide panel kernel
-// Same algorithm as panel_body, generalised to a PW-column panel (PW = 128: half as many
-// panel launches and two of three inner updates per outer block disappear) with OWN rows
-// per workgroup.  The PW x PW diagonal block is kept in LDS as a packed lower trapezoid:
-// row-tile ti (16 rows) stores 16 (ti + 1) + 2 doubles per row, so the 128 x 128 block
-// takes 76 KB instead of 133 KB and leaves room for the own rows and W; the +2 padding
-// keeps MFMA fragment reads conflict-free (row strides of 4 or 36 dwords mod 64).
-template <int PW, int OWN>
-struct PanelLayout {
-  static constexpr int CT = PW / 16;
-  static constexpr int R = PW + OWN;
-  static constexpr int RT = R / 16;
-  static constexpr int DIAG = 128 * CT * (CT + 1) + 32 * CT;
-  static constexpr int OWN_LD = PW + 2;
-  static constexpr int OWND = OWN * OWN_LD;
-  static constexpr int WTD = R * 18;
-  static constexpr int SMEM = (DIAG + OWND + WTD + 2 * PW) * 8 + 16;
-  __device__ __forceinline__ static int off(int row, int col) {
-    if (row < PW) {
-      const int ti = row >> 4;
-      return 128 * ti * (ti + 1) + 32 * ti + (row & 15) * (16 * (ti + 1) + 2) + col;
-    }
-    return DIAG + (row - PW) * OWN_LD + col;
-  }
-};
-
-template <int PW, int OWN>
-__device__ __forceinline__ void panel_body2(unsigned char *smem, const int wg,
-                                            double *__restrict__ K, int64_t ldk,
-                                            double *__restrict__ W, int64_t ldw, int wofs, int N,
-                                            int nrows, int c0, double *__restrict__ dvec,
-                                            double *__restrict__ dinv, int *__restrict__ flags,
-                                            int skip) {
-  using LY = PanelLayout<PW, OWN>;
-  constexpr int CT = LY::CT, R = LY::R, RT = LY::RT;
-  double *M = reinterpret_cast<double *>(smem);
-  double(*Wt)[18] = reinterpret_cast<double(*)[18]>(M + LY::DIAG + LY::OWND);
-  double *dD = M + LY::DIAG + LY::OWND + LY::WTD;
-  double *dI = dD + PW;
-  int &s_bad = *reinterpret_cast<int *>(dI + PW);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l15 = lane & 15, l4 = lane >> 4;
-  const int nb = min(PW, N - c0);
-  const int rbase = c0 + nb + wg * OWN;  // first own row (global)
-  const int coh = (skip >> 3) & 1;
-  if (tid == 0) s_bad = 0;
-
-  // ---- load the diagonal block (lower trapezoid; identity padding beyond nb) ...
-  {
-    constexpr int HP = PW / 2;             // 16-byte pieces per full row
-    constexpr int DP = PW * HP / 256;      // per lane
-    double2_t v[DP];
-#pragma unroll
-    for (int q = 0; q < DP; ++q) {
-      const int p = q * 256 + tid;
-      const int row = p / HP, c2 = (p % HP) * 2;
-      double2_t t = (double2_t){0.0, 0.0};
-      if (c2 < 16 * ((row >> 4) + 1)) {
-        if (row < nb) {
-          const double *src = K + (int64_t)(c0 + row) * ldk + c0 + c2;
-          if (c2 + 1 <= row) t = ld_f64x2(src, coh);
-          else if (c2 <= row) t.x = ld_f64(src, coh);
-        } else {
-          if (c2 == row) t.x = 1.0;
-          if (c2 + 1 == row) t.y = 1.0;
-        }
-      }
-      v[q] = t;
-    }
-#pragma unroll
-    for (int q = 0; q < DP; ++q) {
-      const int p = q * 256 + tid;
-      const int row = p / HP, c2 = (p % HP) * 2;
-      if (c2 < 16 * ((row >> 4) + 1)) *reinterpret_cast<double2_t *>(&M[LY::off(row, c2)]) = v[q];
-    }
-    // ... and the own rows
-    constexpr int OP = OWN * HP / 256;
-    double2_t u[OP];
-#pragma unroll
-    for (int q = 0; q < OP; ++q) {
-      const int p = q * 256 + tid;
-      const int row = p / HP, c2 = (p % HP) * 2;
-      const int r = rbase + row;
-      double2_t t = (double2_t){0.0, 0.0};
-      if (r < nrows) {
-        const double *src = K + (int64_t)r * ldk + c0 + c2;
-        if (c2 + 1 < nb) t = ld_f64x2(src, coh);
-        else if (c2 < nb) t.x = ld_f64(src, coh);
-      }
-      u[q] = t;
-    }
-#pragma unroll
-    for (int q = 0; q < OP; ++q) {
-      const int p = q * 256 + tid;
-      *reinterpret_cast<double2_t *>(&M[LY::off(PW + p / HP, (p % HP) * 2)]) = u[q];
-    }
-  }
-  __syncthreads();
-
-  for (int sb = 0; sb < CT; ++sb) {
-    const int cb = sb * 16;
-    // ---- (a) 16 x 16 diagonal tile: wavefront 0, lane (l & 15) <-> row (every 16-lane row
-    // of the wavefront holds the same tile, so row_newbcast works in all four)
-    double tl[16];  // the factored tile's rows, kept in registers for (b)
-    if (wave == 0 && !(skip & 1)) {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) tl[k] = M[LY::off(cb + l15, cb + k)];
-      double d_mine = 1.0, di_mine = 1.0;
-      int bad_any = 0;
-      tile_factor<0>(tl, l15, cb, nb, d_mine, di_mine, bad_any);
-      if (lane < 16) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-          if (k < lane) M[LY::off(cb + lane, cb + k)] = tl[k];
-        M[LY::off(cb + lane, cb + lane)] = d_mine;
-        dD[cb + lane] = d_mine;
-        dI[cb + lane] = di_mine;
-        if (lane == 0 && bad_any) s_bad = 1;
-      }
-    }
-    __syncthreads();
-    // ---- (b) rows below the tile: substitution, one lane per row; L_bb comes from the
-    // tile registers of the lane's own 16-lane row through row_newbcast (wavefront 0 still
-    // has them from (a); the others reload the factored tile from LDS)
-    {
-      const int row = cb + 16 + wave * 64 + lane;
-      const bool wave_has_rows = (cb + 16 + wave * 64) < R;  // wave-uniform
-      if (wave_has_rows && !(skip & 2)) {
-        if (wave != 0) {
-#pragma unroll
-          for (int k = 0; k < 16; ++k) tl[k] = M[LY::off(cb + l15, cb + k)];
-        }
-        const int rowc = min(row, R - 1);  // lanes past the stack compute on a valid row
-        double x[16];
-        const double *xr = &M[LY::off(rowc, cb)];
-#pragma unroll
-        for (int k = 0; k < 16; k += 2) {
-          const double2_t v = *reinterpret_cast<const double2_t *>(xr + k);
-          x[k] = v.x;
-          x[k + 1] = v.y;
-        }
-        subst_rows<0>(x, tl);
-        if (row < R) {
-        double *xw = &M[LY::off(row, cb)];
-#pragma unroll
-        for (int k = 0; k < 16; k += 2) {
-          double2_t w, l;
-          w.x = x[k];
-          w.y = x[k + 1];
-          l.x = x[k] * dI[cb + k];
-          l.y = x[k + 1] * dI[cb + k + 1];
-          *reinterpret_cast<double2_t *>(&Wt[row][k]) = w;
-          *reinterpret_cast<double2_t *>(xw + k) = l;
-        }
-        if (row >= PW) {
-          const int r = rbase + row - PW;
-          if (r < nrows) {
-            double *wp = W + (int64_t)r * ldw + wofs + cb;
-#pragma unroll
-            for (int k = 0; k < 16; k += 2) {
-              double2_t w;
-              w.x = x[k];
-              w.y = x[k + 1];
-              st_f64x2(wp + k, w, coh);
-            }
-          }
-        }
-        }
-      }
-    }
-    __syncthreads();
-    // ---- (c) tiles to the right: M[ti][tj] -= W[ti] L[tj]^T, tj in (sb, CT), ti in [tj, RT)
-    if (sb + 1 < CT && !(skip & 4)) {
-      int total = 0;
-      for (int tj = sb + 1; tj < CT; ++tj) total += RT - tj;
-      for (int e0 = wave; e0 < total; e0 += 4) {
-        int e = e0, tj = sb + 1;
-        while (e >= RT - tj) {
-          e -= RT - tj;
-          ++tj;
-        }
-        const int ti = tj + e;
-        double4_t acc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = M[LY::off(ti * 16 + l4 + 4 * r, tj * 16 + l15)];
-#pragma unroll
-        for (int ks = 0; ks < 16; ks += 4) {
-          const double av = -Wt[ti * 16 + l15][ks + l4];
-          const double bv = M[LY::off(tj * 16 + l15, cb + ks + l4)];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) M[LY::off(ti * 16 + l4 + 4 * r, tj * 16 + l15)] = acc[r];
-      }
-    }
-    __syncthreads();
-  }
-
-  // ---- write back: own rows (L), and by workgroup 0 the factored diagonal block
-  {
-    constexpr int HP = PW / 2;
-    for (int p = tid; p < OWN * HP; p += 256) {
-      const int row = p / HP, c2 = (p % HP) * 2;
-      const int r = rbase + row;
-      if (r < nrows) {
-        const double2_t v = *reinterpret_cast<const double2_t *>(&M[LY::off(PW + row, c2)]);
-        double *dst = K + (int64_t)r * ldk + c0 + c2;
-        if (c2 + 1 < nb) st_f64x2(dst, v, coh);
-        else if (c2 < nb) st_f64(dst, v.x, coh);
-      }
-    }
-  }
-  if (wg == 0) {
-    for (int p = tid; p < PW * PW; p += 256) {
-      const int row = p / PW, c = p % PW;
-      if (row < nb && c <= row) st_f64(K + (int64_t)(c0 + row) * ldk + c0 + c, M[LY::off(row, c)], coh);
-    }
-    for (int i = tid; i < nb; i += 256) {
-      st_f64(dvec + c0 + i, dD[i], coh);
-      st_f64(dinv + c0 + i, dI[i], coh);
-    }
-    if (wave == 0) {
-      int neg = 0;
-      for (int i = lane; i < nb; i += 64) neg += (dD[i] < 0.0) ? 1 : 0;
-      for (int o = 32; o > 0; o >>= 1) neg += __shfl_down(neg, o);
-      if (lane == 0) {
-        if (s_bad) atomicOr(&flags[0], 1);
-        if (neg) atomicAdd(&flags[1], neg);
-      }
-    }
-  }
-}
-
-template <int PW, int OWN>
-__global__ __launch_bounds__(256) void k_ldlt_panel2(double *__restrict__ K, int64_t ldk,
-                                                     double *__restrict__ W, int64_t ldw, int wofs,
-                                                     int N, int nrows, int c0,
-                                                     double *__restrict__ dvec,
-                                                     double *__restrict__ dinv,
-                                                     int *__restrict__ flags, int skip) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[PanelLayout<PW, OWN>::SMEM];
-  panel_body2<PW, OWN>(smem, blockIdx.x, K, ldk, W, ldw, wofs, N, nrows, c0, dvec, dinv, flags,
-                       skip);
+  update_tile<BM, BN, BK, WR, WC, DB>(smem, threadIdx.x, i0, j0, K, ldk, W, ldw, N, nrows, colEnd, kc0,
+                                      KB);
 }
 
 template <int NB>
@@ -886,33 +315,6 @@ __global__ __launch_bounds__(256) void k_ldlt_panel(double *__restrict__ K, int6
                                                     int *__restrict__ flags, int skip) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[PNL_SMEM];
   panel_body<NB>(smem, blockIdx.x, K, ldk, W, ldw, wofs, N, nrows, c0, dvec, dinv, flags, skip);
-}
-
-// Panel launch that also carries "filler" workgroups: 128 x 128 tiles of the PREVIOUS outer
-// block's bulk trailing update (columns beyond the current outer block), which touch
-// nothing the panel reads or writes.  This is the look-ahead of the blocked
-// factorisation, obtained inside one queue: the CUs the panel cannot use (it has ~N/64
-// workgroups and is latency-bound) run MFMA tiles instead of idling.  No data is handed
-// between workgroups of the launch, so ordinary kernel-boundary visibility suffices.
-// Tiles are numbered over the lower triangle of the region: t -> (ti, tj), tj <= ti.
-template <int NB>
-__global__ __launch_bounds__(256, 2) void k_ldlt_panel_fused(
-    double *__restrict__ K, int64_t ldk, double *__restrict__ W, int64_t ldw, int wofs, int N,
-    int nrows, int c0, double *__restrict__ dvec, double *__restrict__ dinv,
-    int *__restrict__ flags, int skip, int n_panel_wg, const double *__restrict__ Wprev,
-    int64_t ldwp, int ureg0, int ukc0, int uKB, int tile_start) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[PNL_SMEM];
-  if ((int)blockIdx.x < n_panel_wg) {
-    panel_body<NB>(smem, blockIdx.x, K, ldk, W, ldw, wofs, N, nrows, c0, dvec, dinv, flags, skip);
-  } else {
-    const int t = tile_start + (int)blockIdx.x - n_panel_wg;
-    int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    while (ti * (ti + 1) / 2 > t) --ti;
-    const int tj = t - ti * (ti + 1) / 2;
-    update_tile<UPD_BM, UPD_BM, 16>(smem, ureg0 + ti * UPD_BM, ureg0 + tj * UPD_BM, K, ldk, Wprev,
-                                    ldwp, N, nrows, N, ukc0, uKB);
-  }
 }
 
 // ------------------------------------------------------------------ triangular solves
@@ -1222,7 +624,10 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_chain(const double *__restrict
     const double xv = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
     if (b0 + lane < N)
       __hip_atomic_store(x + b0 + lane, xv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // the write-through (sc1) stores above must have left this wavefront before the stamp
+    // does: two stores of one wavefront to different L2 channels are not ordered otherwise
+    // (inline asm: the compiler may drop a builtin wait it believes redundant)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0)
       __hip_atomic_store(stamps + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -1292,7 +697,10 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_chain(const double *__restrict
     const double xv = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
     if (b0 + lane < N)
       __hip_atomic_store(x + b0 + lane, xv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // the write-through (sc1) stores above must have left this wavefront before the stamp
+    // does: two stores of one wavefront to different L2 channels are not ordered otherwise
+    // (inline asm: the compiler may drop a builtin wait it believes redundant)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0)
       __hip_atomic_store(stamps + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -1351,8 +759,8 @@ __global__ __launch_bounds__(256) void kb_ldlt_update(const BInst *__restrict__ 
   const int i0 = row0 + by * 64;
   const int j0 = col0 + bx * 64;
   if (i0 >= nrows || j0 >= colEnd || j0 > i0 + 63) return;
-  update_tile<64, 64, 16>(smem, i0, j0, I.K, I.ldk, I.W + (int64_t)wbuf * I.wstride + wcol, ldw, N,
-                          nrows, colEnd, kc0, KB);
+  update_tile<64, 64, 16>(smem, threadIdx.x, i0, j0, I.K, I.ldk,
+                          I.W + (int64_t)wbuf * I.wstride + wcol, ldw, N, nrows, colEnd, kc0, KB);
 }
 
 // ---- left-looking panel step of the batched schedule --------------------------------------
@@ -1800,24 +1208,14 @@ hipError_t ldlt_alloc(DenseLdlt &f, int Nmax, hipStream_t stream) {
   f.stream = stream;
   hipError_t e;
   const size_t rows = (size_t)Nmax + 1 + PGF_NB;
-  // PGF_FINEGRAINED=1 (diagnostic): K and W in fine-grained device memory, i.e. coherent
-  // across the XCDs' L2s without kernel-boundary cache maintenance
-  const bool fg = getenv("PGF_FINEGRAINED") != nullptr;
-  auto dmalloc = [&](double **ptr, size_t bytes) {
-    return fg ? hipExtMallocWithFlags((void **)ptr, bytes, hipDeviceMallocFinegrained)
-              : hipMalloc((void **)ptr, bytes);
-  };
-  if ((e = dmalloc(&f.K, rows * f.ldk * sizeof(double))) != hipSuccess) return e;
+  if ((e = hipMalloc((void **)&f.K, rows * f.ldk * sizeof(double))) != hipSuccess) return e;
   f.OB = 256;
-  if (const char *ob = getenv("PGF_OB")) {
+  if (const char *ob = getenv("PGF_OB")) {  // legacy schedule only (PGF_FACTOR=1)
     const int v = atoi(ob);
     if (v == 64 || v == 128 || v == 192 || v == 256) f.OB = v;
   }
-  f.wstride = rows * (size_t)f.OB;
-  if ((e = dmalloc(&f.W, 2 * f.wstride * sizeof(double))) != hipSuccess) return e;
-  if ((e = hipStreamCreateWithFlags(&f.stream2, hipStreamNonBlocking)) != hipSuccess) return e;
-  if ((e = hipEventCreateWithFlags(&f.ev_panel, hipEventDisableTiming)) != hipSuccess) return e;
-  if ((e = hipEventCreateWithFlags(&f.ev_update, hipEventDisableTiming)) != hipSuccess) return e;
+  f.wstride = rows * (size_t)256;
+  if ((e = hipMalloc((void **)&f.W, 2 * f.wstride * sizeof(double))) != hipSuccess) return e;
   if ((e = hipMalloc(&f.dvec, rows * sizeof(double))) != hipSuccess) return e;
   if ((e = hipMalloc(&f.dinv, rows * sizeof(double))) != hipSuccess) return e;
   if ((e = hipMalloc(&f.zwork, rows * sizeof(double))) != hipSuccess) return e;
@@ -1843,14 +1241,10 @@ void ldlt_free(DenseLdlt &f) {
   if (f.flags) (void)hipFree(f.flags);
   if (f.chain) (void)hipFree(f.chain);
   if (f.h_flags) (void)hipHostFree(f.h_flags);
-  if (f.ev_panel) (void)hipEventDestroy(f.ev_panel);
-  if (f.ev_update) (void)hipEventDestroy(f.ev_update);
-  for (hipEvent_t ev : f.ev_ring) (void)hipEventDestroy(ev);
-  if (f.stream2) (void)hipStreamDestroy(f.stream2);
   f = DenseLdlt();
 }
 
-static hipEvent_t prof_event(PgfProfile *p) {
+hipEvent_t prof_event(PgfProfile *p) {
   if (!p->pool.empty()) {
     hipEvent_t e = p->pool.back();
     p->pool.pop_back();
@@ -1863,9 +1257,12 @@ static hipEvent_t prof_event(PgfProfile *p) {
 
 // Launch one trailing-update region (see k_ldlt_update) on stream `s`, optionally
 // bracketed by profiling events.
-static void launch_update(DenseLdlt &f, hipStream_t s, const double *Wp, int64_t ldw, int N,
-                          int nrows, int row0, int col0, int colEnd, int kc0, int KB,
-                          PgfProfile *p, int coh = 0) {
+// any_order: launched with hipExtAnyOrderLaunch, i.e. without the barrier that makes a launch
+// wait for the packets queued before it (it then runs beside the previous kernel of the
+// stream; the NEXT ordinary launch still waits for both).  Ignored while profiling.
+void launch_update(DenseLdlt &f, hipStream_t s, const double *Wp, int64_t ldw, int N,
+                   int nrows, int row0, int col0, int colEnd, int kc0, int KB,
+                   PgfProfile *p, int any_order) {
   if (row0 >= nrows || col0 >= colEnd) return;
   // 64 x 64 tiles (96 VGPRs, 5 wavefronts per SIMD) beat 128 x 128 tiles (249 VGPRs, 2 per
   // SIMD) at every region size measured (tools/bench_update.py): the kernel lives on
@@ -1879,8 +1276,13 @@ static void launch_update(DenseLdlt &f, hipStream_t s, const double *Wp, int64_t
     e1 = prof_event(p);
     (void)hipEventRecord(e0, s);
   }
-  hipLaunchKernelGGL((k_ldlt_update<64, 64, 16>), dim3(tc, tr), dim3(256), 0, s, f.K, f.ldk, Wp,
-                     ldw, N, nrows, row0, col0, colEnd, kc0, KB | (coh << 20));
+  if (any_order && !p)
+    hipExtLaunchKernelGGL((k_ldlt_update<64, 64, 16>), dim3(tc, tr), dim3(256), 0, s, nullptr,
+                          nullptr, hipExtAnyOrderLaunch, f.K, f.ldk, Wp, ldw, N, nrows, row0, col0,
+                          colEnd, kc0, KB);
+  else
+    hipLaunchKernelGGL((k_ldlt_update<64, 64, 16>), dim3(tc, tr), dim3(256), 0, s, f.K, f.ldk, Wp,
+                       ldw, N, nrows, row0, col0, colEnd, kc0, KB);
   if (p) {
     (void)hipEventRecord(e1, s);
     p->update_spans.emplace_back(e0, e1);
@@ -1896,102 +1298,17 @@ static void launch_update(DenseLdlt &f, hipStream_t s, const double *Wp, int64_t
   }
 }
 
-// ------------------------------------------------------------------ overlapped schedule
-// Look-ahead inside ONE queue.  A kernel launched with hipExtAnyOrderLaunch does not wait for
-// the packets before it (tools/launch_gap_test.hip: it really runs unordered on this stack),
-// so after every panel launch of outer block i + 1 a PIECE of outer block i's bulk trailing
-// update is launched any-order and runs beside that panel:
-//     U_next(i)                      columns of block i + 1, normal launch
-//     P0(i+1) | piece 0 of B_i       P0 normal, the piece any-order
-//     P1(i+1) | piece 1 of B_i       P1's barrier waits for P0 AND piece 0, then both start
-//     ...
-//     fence kernel                   normal; its end-of-kernel release writes the last
-//                                    piece's C tiles back before the next block reads them
-// The pieces touch only columns >= nextEnd, the panels of block i + 1 only their own columns
-// and the other W buffer, so a pair never shares data.  Everything a piece reads was written
-// at least two ordinary kernel boundaries earlier; only the panels, which hand data from one
-// to the next across XCDs, keep the ordinary (fenced) launch.
-__global__ void k_fence() {}
-
-static void launch_piece(DenseLdlt &f, hipStream_t s, const double *Wp, int64_t ldw, int N,
-                         int row_lo, int row_hi, int col0, int kc0, int KB) {
-  if (row_lo >= row_hi || col0 >= N) return;
-  const int tr = (row_hi - row_lo + 63) / 64;
-  const int tc = (std::min(N, row_hi) - col0 + 63) / 64;
-  if (tc <= 0) return;
-  hipExtLaunchKernelGGL((k_ldlt_update<64, 64, 16>), dim3(tc, tr), dim3(256), 0, s, nullptr,
-                        nullptr, hipExtAnyOrderLaunch, f.K, f.ldk, Wp, ldw, N, row_hi, row_lo, col0,
-                        N, kc0, KB);
-}
-
-static void factor_overlapped(DenseLdlt &f, int N, int nrows) {
-  // Per outer block i (bulk update B_i = strip A: the next block's columns, + far region):
-  //   A (ordinary) | B1 (any-order)   the strip alone under-fills the chip; B1 = the first
-  //                                    ~FILL tiles of the far region runs beside it
-  //   P0 (ordinary: waits for A, B1) | B2 (any-order) = the rest of the far region
-  //   P1 (ordinary: waits for P0, B2), P2, P3
-  // Ordinary launches end with a cache release, and each one here starts only after the
-  // any-order piece before it has completed, so every piece's C tiles are written back
-  // before anything reads them.
-  hipStream_t s = f.stream;
-  const int OB = f.OB;
-  const int FILL = getenv("PGF_OVERLAP_FILL") ? atoi(getenv("PGF_OVERLAP_FILL")) : 1000;
-  struct {
-    bool active = false;
-    const double *Wp = nullptr;
-    int reg0 = 0, kc0 = 0, KB = 0, r1 = 0;
-  } pend;
-  int buf = 0;
-  for (int ob0 = 0; ob0 < N; ob0 += OB, buf ^= 1) {
-    const int obEnd = std::min(ob0 + OB, N);
-    double *Wb = f.W + (size_t)buf * f.wstride;
-    int k = 0;
-    for (int c0 = ob0; c0 < obEnd; c0 += PGF_NB, ++k) {
-      const int below = nrows - std::min(c0 + PGF_NB, N);
-      const int npw = std::max(1, (below + 63) / 64);
-      hipLaunchKernelGGL(k_ldlt_panel_ll<PGF_NB>, dim3(npw), dim3(256), 0, s, f.K, f.ldk, Wb,
-                         (int64_t)OB, ob0, N, nrows, c0, f.dvec, f.dinv, f.flags);
-      if (k == 0 && pend.active) {  // B2 of the previous block beside this block's first panel
-        launch_piece(f, s, pend.Wp, OB, N, pend.r1, nrows, pend.reg0, pend.kc0, pend.KB);
-        pend.active = false;
-      }
-    }
-    if (obEnd < N) {
-      const int KB = obEnd - ob0;
-      const int nextEnd = std::min(obEnd + OB, N);
-      launch_update(f, s, Wb, OB, N, nrows, obEnd, obEnd, nextEnd, ob0, KB, nullptr, 0);  // A
-      if (nextEnd < N) {
-        // far region: rows / columns >= nextEnd; B1 = its first tile rows holding ~FILL tiles
-        const int TR = (nrows - nextEnd + 63) / 64;
-        int t1 = (int)std::ceil((std::sqrt(8.0 * FILL + 1.0) - 1.0) * 0.5);
-        t1 = std::max(1, std::min(TR, t1));
-        const int r1 = std::min(nrows, nextEnd + t1 * 64);
-        launch_piece(f, s, Wb, OB, N, nextEnd, r1, nextEnd, ob0, KB);  // B1
-        if (r1 < nrows) {
-          pend.active = true;
-          pend.Wp = Wb;
-          pend.reg0 = nextEnd;
-          pend.kc0 = ob0;
-          pend.KB = KB;
-          pend.r1 = r1;
-        }
-      }
-    }
-  }
-}
-
-// Two-level factorisation, the schedule of one call (default path, one queue):
+// Two-level factorisation, the schedule of one call (one queue):
 //   per outer block of f.OB = 256 columns:
 //     4 x k_ldlt_panel_ll   64-column panels, left-looking inside the block: a panel's
 //                           prologue applies the earlier panels of the block to the two tiles
 //                           it needs, so nothing is launched between them
 //     1 x k_ldlt_update     bulk right-looking update of everything to the right, K = 256
 //   k_inv_diag_blocks       inverses of the 64 x 64 diagonal blocks for the solves
-// W (= L D of the current outer block, OB columns wide) is double buffered: the experimental
-// overlapped / look-ahead schedules still read block i's W while block i + 1 writes its own.
-// The branches behind PGF_LOOKAHEAD, PGF_FUSE, PGF_OVERLAP, PGF_PANEL_LL=0, PGF_PW and
-// PGF_PANEL2 are the experiments DESIGN.md describes; none of them is the default.
+// This is the round-1 schedule, kept as the reference schedule (PGF_FACTOR=1) for the
+// look-ahead schedule of pgf_factor2.hip, which is the default.
 hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
+  if (ldlt_use_lookahead()) return ldlt_factor2_async(f, N, nrows);
   f.N = N;
   f.factored = false;
   hipStream_t sA = f.stream;
@@ -2002,189 +1319,20 @@ hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows) {
     p->factor_spans.emplace_back(prof_event(p), prof_event(p));
     (void)hipEventRecord(p->factor_spans.back().first, sA);
   }
-  // PGF_OVERLAP=1: any-order look-ahead inside the one queue (factor_overlapped); the
-  // instrumented pass (events around every update launch) keeps the plain schedule
-  if (getenv("PGF_OVERLAP") && atoi(getenv("PGF_OVERLAP")) != 0 && !p &&
-      !getenv("PGF_LOOKAHEAD") && !getenv("PGF_FUSE")) {
-    factor_overlapped(f, N, nrows);
-    if (N > 0)
-      hipLaunchKernelGGL(k_inv_diag_blocks, dim3((N + 63) / 64), dim3(64), 0, sA, f.K, f.ldk, N,
-                         f.Linv, f.LinvT);
-    e = hipMemcpyAsync(f.h_flags, f.flags, 2 * sizeof(int), hipMemcpyDeviceToHost, sA);
-    if (e != hipSuccess) return e;
-    return hipGetLastError();
-  }
   const int OB = f.OB;
-  // PGF_LOOKAHEAD=1: bulk update of outer block i on a second stream, overlapped with the
-  // panels of block i + 1; PGF_COHERENT (default 1 with look-ahead): stream-A kernels and
-  // (bit 1) the bulk kernel load with system scope, see ld_f64
-  const bool la = getenv("PGF_LOOKAHEAD") != nullptr;
-  const int cohm = getenv("PGF_COHERENT") ? atoi(getenv("PGF_COHERENT")) : 0;
-  const int cohA = cohm & 1, cohB = (cohm >> 1) & 1;
-  // PGF_LA_ONEQ: the look-ahead launch sequence on ONE queue (separates schedule logic from
-  // multi-queue effects)
-  hipStream_t sB = (la && !getenv("PGF_LA_ONEQ")) ? f.stream2 : f.stream;
-  int evi = 0;
-  auto next_event = [&]() -> hipEvent_t {
-    if ((size_t)evi >= f.ev_ring.size()) {
-      hipEvent_t ev;
-      (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-      f.ev_ring.push_back(ev);
-    }
-    return f.ev_ring[evi++];
-  };
-  hipEvent_t ev_b_done = nullptr;
-  bool b_pending = false;
-  if (la) {  // stream B must not start before everything already queued on A
-    hipEvent_t ev0 = next_event();
-    (void)hipEventRecord(ev0, sA);
-    (void)hipStreamWaitEvent(sB, ev0, 0);
-  }
-  const int la_dbg = getenv("PGF_LA_DEBUG") ? atoi(getenv("PGF_LA_DEBUG")) : 0;
-  // panel width: 128 (wide kernel, 32 own rows per workgroup) or 64
-  const int pw_env = getenv("PGF_PW") ? atoi(getenv("PGF_PW")) : 64;
-  const bool pnl2 = getenv("PGF_PANEL2") != nullptr;  // 64-wide panel through the new body
-  const int PWh = (pw_env == 128 && OB % 128 == 0 && getenv("PGF_FUSE") == nullptr) ? 128 : 64;
-  const int OWNh = (PWh == 128) ? 32 : 64;
-  // left-looking panels inside the outer block (no K = 64 update launches): the default on the
-  // single-queue schedule; PGF_PANEL_LL=0 brings the separate inner updates back
-  const bool pnl_ll = !(getenv("PGF_PANEL_LL") && atoi(getenv("PGF_PANEL_LL")) == 0) && !la &&
-                      getenv("PGF_FUSE") == nullptr && PWh == 64 && !pnl2;
-  // With a second queue active, consecutive kernels of ONE stream were observed to overlap
-  // (the last workgroups of an inner update still running when the next panel started:
-  // wrong factors, periodic in 8 workgroups).  An explicit record + wait on the same stream
-  // between dependent launches restores the in-order semantics; without look-ahead (one
-  // queue) it is not needed.
-  auto fence_on = [&](hipStream_t st) {
-    hipEvent_t ev = next_event();
-    (void)hipEventRecord(ev, st);
-    (void)hipStreamWaitEvent(st, ev, 0);
-  };
-  // PGF_LA_DEBUG: 9 = no extra fences at all, 10 = only at the cross-queue edges
-  auto self_fence = [&]() {
-    if (la && la_dbg != 9 && la_dbg != 10) fence_on(sA);
-  };
-  auto edge_fence = [&](hipStream_t st) {
-    if (la && la_dbg == 10) fence_on(st);
-  };
-  const int skip = (getenv("PGF_SKIP") ? atoi(getenv("PGF_SKIP")) : 0) | (cohA << 3);
-  // filler tiles in the panel launches: correct, but not yet a win (the panel's 87 KB of
-  // LDS leaves one filler workgroup per CU, and the tile kernel needs several per SIMD)
-  const bool fuse = getenv("PGF_FUSE") != nullptr;
-  // pending bulk update (previous outer block): region [reg0, nrows) x [reg0, N)
-  struct {
-    bool active = false;
-    const double *Wp = nullptr;
-    int reg0 = 0, kc0 = 0, KB = 0, total = 0, done = 0;
-  } pend;
   int buf = 0;
   for (int ob0 = 0; ob0 < N; ob0 += OB, buf ^= 1) {
     const int obEnd = std::min(ob0 + OB, N);
     double *Wb = f.W + (size_t)buf * f.wstride;
-    const int npanels = (obEnd - ob0 + PWh - 1) / PWh;
-    int k = 0;
-    for (int c0 = ob0; c0 < obEnd; c0 += PWh, ++k) {
-      const int below = nrows - std::min(c0 + PWh, N);
-      const int npw = std::max(1, (below + OWNh - 1) / OWNh);
-      const int remaining = pend.active ? pend.total - pend.done : 0;
-      if (remaining > 0) {
-        const int share = (remaining + (npanels - k) - 1) / (npanels - k);
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (p) {
-          e0 = prof_event(p);
-          e1 = prof_event(p);
-          (void)hipEventRecord(e0, sA);
-        }
-        hipLaunchKernelGGL(k_ldlt_panel_fused<PGF_NB>, dim3(npw + share), dim3(256), 0, sA, f.K,
-                           f.ldk, Wb, (int64_t)OB, c0 - ob0, N, nrows, c0, f.dvec, f.dinv, f.flags,
-                           skip, npw, pend.Wp, (int64_t)OB, pend.reg0, pend.kc0, pend.KB,
-                           pend.done);
-        if (p) {
-          (void)hipEventRecord(e1, sA);
-          p->update_spans.emplace_back(e0, e1);
-          // algorithmic flops of the filler tiles of this launch (lower triangle only)
-          double cnt = 0.0;
-          for (int t = pend.done; t < pend.done + share; ++t) {
-            int ti = (int)((std::sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-            while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-            while (ti * (ti + 1) / 2 > t) --ti;
-            const int tj = t - ti * (ti + 1) / 2;
-            const int r0 = pend.reg0 + ti * UPD_BM, c0t = pend.reg0 + tj * UPD_BM;
-            const int r1 = std::min(r0 + UPD_BM, nrows), c1t = std::min(c0t + UPD_BM, N);
-            for (int i = r0; i < r1; ++i) {
-              const int top = std::min(c1t, i + 1);
-              if (top > c0t) cnt += top - c0t;
-            }
-          }
-          p->update_flops.push_back(2.0 * cnt * pend.KB);
-        }
-        pend.done += share;
-      } else if (PWh == 128) {
-        hipLaunchKernelGGL((k_ldlt_panel2<128, 32>), dim3(npw), dim3(256), 0, sA, f.K, f.ldk, Wb,
-                           (int64_t)OB, c0 - ob0, N, nrows, c0, f.dvec, f.dinv, f.flags, skip);
-      } else if (pnl2) {
-        hipLaunchKernelGGL((k_ldlt_panel2<64, 64>), dim3(npw), dim3(256), 0, sA, f.K, f.ldk, Wb,
-                           (int64_t)OB, c0 - ob0, N, nrows, c0, f.dvec, f.dinv, f.flags, skip);
-      } else if (pnl_ll) {
-        hipLaunchKernelGGL(k_ldlt_panel_ll<PGF_NB>, dim3(npw), dim3(256), 0, sA, f.K, f.ldk, Wb,
-                           (int64_t)OB, ob0, N, nrows, c0, f.dvec, f.dinv, f.flags);
-        continue;  // no inner updates: the next panel's prologue applies this one
-      } else {
-        hipLaunchKernelGGL(k_ldlt_panel<PGF_NB>, dim3(npw), dim3(256), 0, sA, f.K, f.ldk, Wb,
-                           (int64_t)OB, c0 - ob0, N, nrows, c0, f.dvec, f.dinv, f.flags, skip);
-      }
-      const int c1 = c0 + PWh;
-      self_fence();
-      if (c1 < obEnd)  // inner update: the rest of this outer block's columns, K = panel width
-        launch_update(f, sA, Wb + (c0 - ob0), OB, N, nrows, c1, c1, obEnd, c0, PWh, p, cohA);
-      self_fence();
+    for (int c0 = ob0; c0 < obEnd; c0 += PGF_NB) {
+      const int below = nrows - std::min(c0 + PGF_NB, N);
+      const int npw = std::max(1, (below + 63) / 64);
+      hipLaunchKernelGGL(k_ldlt_panel_ll<PGF_NB>, dim3(npw), dim3(256), 0, sA, f.K, f.ldk, Wb,
+                         (int64_t)OB, ob0, N, nrows, c0, f.dvec, f.dinv, f.flags);
     }
-    pend.active = false;
-    if (obEnd < N) {
-      const int KB = obEnd - ob0;  // == OB here (only the last outer block may be short)
-      const int nextEnd = std::min(obEnd + OB, N);
-      if (!la && !fuse) {
-        // one queue, no look-ahead: nothing is gained by splitting off the next block's
-        // columns -- update the whole trailing matrix in one (large, efficient) launch
-        launch_update(f, sA, Wb, OB, N, nrows, obEnd, obEnd, N, ob0, KB, p, 0);
-        continue;
-      }
-      if (la && b_pending) {
-        (void)hipStreamWaitEvent(sA, ev_b_done, 0);  // RMW order
-        edge_fence(sA);
-      }
-      launch_update(f, sA, Wb, OB, N, nrows, obEnd, obEnd, nextEnd, ob0, KB, p, cohA);
-      self_fence();
-      if (nextEnd < N) {
-        if (la) {
-          hipEvent_t ev_a = next_event();
-          (void)hipEventRecord(ev_a, sA);
-          (void)hipStreamWaitEvent(sB, ev_a, 0);
-          edge_fence(sB);
-          launch_update(f, sB, Wb, OB, N, nrows, nextEnd, nextEnd, N, ob0, KB, p, cohB);
-          ev_b_done = next_event();
-          (void)hipEventRecord(ev_b_done, sB);
-          b_pending = true;
-        } else if (fuse) {
-          const int TR = (nrows - nextEnd + UPD_BM - 1) / UPD_BM;
-          pend.active = true;
-          pend.Wp = Wb;
-          pend.reg0 = nextEnd;
-          pend.kc0 = ob0;
-          pend.KB = KB;
-          pend.total = TR * (TR + 1) / 2;
-          pend.done = 0;
-        } else {
-          launch_update(f, sA, Wb, OB, N, nrows, nextEnd, nextEnd, N, ob0, KB, p);
-        }
-      }
-    }
+    if (obEnd < N)  // bulk update of the whole trailing matrix, K-depth = the block width
+      launch_update(f, sA, Wb, OB, N, nrows, obEnd, obEnd, N, ob0, obEnd - ob0, p, 0);
   }
-  if (la && b_pending) {
-    (void)hipStreamWaitEvent(sA, ev_b_done, 0);
-    edge_fence(sA);
-  }
-  self_fence();
   if (N > 0)
     hipLaunchKernelGGL(k_inv_diag_blocks, dim3((N + 63) / 64), dim3(64), 0, sA, f.K, f.ldk, N,
                        f.Linv, f.LinvT);
@@ -2200,6 +1348,7 @@ int ldlt_finish(DenseLdlt &f, hipError_t *err) {
   if (e != hipSuccess) return -1;
   f.n_neg = f.h_flags[1];
   f.factored = (f.h_flags[0] == 0);
+  ldlt_chain_timing_dump();  // no-op unless PGF_CHAIN_TIMING is set
   if (f.h_flags[0]) return 1;
   return ldlt_chain_check(f) ? 2 : 0;
 }
@@ -2361,14 +1510,7 @@ hipError_t ldlt_bench_update(int N, int KB, int variant, int reps, double *ms_ou
   f.ldk = pick_ldk(N + KB);
   f.stream = s;
   const size_t rows = (size_t)N + KB + 1;
-  // PGF_FINEGRAINED=1 (diagnostic): K and W in fine-grained device memory, i.e. coherent
-  // across the XCDs' L2s without kernel-boundary cache maintenance
-  const bool fg = getenv("PGF_FINEGRAINED") != nullptr;
-  auto dmalloc = [&](double **ptr, size_t bytes) {
-    return fg ? hipExtMallocWithFlags((void **)ptr, bytes, hipDeviceMallocFinegrained)
-              : hipMalloc((void **)ptr, bytes);
-  };
-  if ((e = dmalloc(&f.K, rows * f.ldk * sizeof(double))) != hipSuccess) return e;
+  if ((e = hipMalloc((void **)&f.K, rows * f.ldk * sizeof(double))) != hipSuccess) return e;
   if ((e = hipMalloc(&f.W, rows * KB * sizeof(double))) != hipSuccess) return e;
   hipLaunchKernelGGL(k_fill_pattern, dim3((rows * f.ldk + 255) / 256), dim3(256), 0, s, f.K,
                      rows * f.ldk, 1.0);
@@ -2384,14 +1526,8 @@ hipError_t ldlt_bench_update(int N, int KB, int variant, int reps, double *ms_ou
     const int KBx = KB;
     switch (variant) {
       case 0: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2, 0); break;
-      case 1: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2, 2); break;
-      case 2: PGF_LAUNCH_VARIANT(128, 128, 16, 2, 2, 2); break;
-      case 3: PGF_LAUNCH_VARIANT(128, 128, 16, 4, 4, 2); break;
-      case 4: PGF_LAUNCH_VARIANT(128, 128, 16, 2, 4, 2); break;
-      case 5: PGF_LAUNCH_VARIANT(128, 64, 16, 2, 2, 2); break;
-      case 6: PGF_LAUNCH_VARIANT(128, 64, 16, 4, 2, 2); break;
-      case 7: PGF_LAUNCH_VARIANT(128, 128, 32, 2, 4, 2); break;
-      case 8: PGF_LAUNCH_VARIANT(64, 128, 16, 2, 2, 2); break;
+      case 1: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2, 1); break;
+      case 3: PGF_LAUNCH_VARIANT(128, 128, 16, 4, 4, 1); break;
       case 9: PGF_LAUNCH_VARIANT(64, 64, 64, 2, 2, 0); break;
       case 10: PGF_LAUNCH_VARIANT(64, 64, 32, 2, 2, 0); break;
       default: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2, 0); break;

@@ -15,6 +15,10 @@ try:  # drop-in inside a pygradflow installation
 except Exception:  # stand-alone (e.g. on the GPU box)
     _RefLinearSolverError = Exception
     _RefStepSolverError = Exception
+try:
+    from pygradflow.eval import EvalError as _RefEvalError
+except Exception:
+    _RefEvalError = ValueError
 
 
 class LinearSolverError(_RefLinearSolverError):
@@ -23,3 +27,18 @@ class LinearSolverError(_RefLinearSolverError):
 
 class StepSolverError(_RefStepSolverError):
     """The step solver failed, e.g. because the Newton matrix is (near) singular."""
+
+
+class EvalError(_RefEvalError):
+    """A problem callback failed or returned non-finite values at ``x`` (reference
+    ``pygradflow/eval.py:18-21``); step controllers reject the step and halve ``dt``
+    (``step/step_control.py:103-107``)."""
+
+    def __init__(self, msg, x=None):
+        self.x = x
+        ValueError.__init__(self, msg)
+
+
+# what StepController.compute_step turns into "reject, lambda <- 2 lambda": our classes and,
+# when the reference is importable, its own (an evaluator of the reference raises those)
+STEP_FAILURES = tuple({StepSolverError, EvalError, _RefEvalError} - {ValueError, Exception})

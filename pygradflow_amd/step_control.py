@@ -24,7 +24,7 @@ import abc
 import numpy as np
 
 from .controller import ControllerSettings, LogController
-from .errors import StepSolverError
+from .errors import STEP_FAILURES, StepSolverError  # noqa: F401
 from .newton import newton_method
 from .params import enum_name
 
@@ -79,7 +79,7 @@ class StepController(abc.ABC):
             if result.accepted and hasattr(result.iterate, "check_eval"):
                 result.iterate.check_eval()
             return result
-        except StepSolverError:
+        except STEP_FAILURES:  # StepSolverError and EvalError (step_control.py:103-107)
             lamb = self.update_stepsize_after_fail(1.0 / dt)
             return StepControlResult(iterate, lamb, None, None, False)
 

@@ -140,8 +140,11 @@ def test_device_resident_newton(pgf, name):
             assert G.rel_err(y, case[pre + "yn"]) <= TOL, (pol, k)
             assert abs(diff - float(case[pre + "diff"])) <= TOL * max(1.0, diff)
             assert n_neg == int(case[pre + "n_neg"])
-            assert abs(dn.residual_norm() - float(case[pre + "res_norm"])) <= 1e-9 * max(
-                1.0, float(case[pre + "res_norm"]))
+            # ||F(z+)|| after a Newton step is a difference of terms of size ||H|| ||x||: its
+            # rounding noise scales with that (it matters for the hard_* cases only)
+            scale = max(1.0, float(case[pre + "res_norm"]),
+                        float(np.abs(problem.hess_dense()).sum(axis=1).max() * np.abs(x).max()))
+            assert abs(dn.residual_norm() - float(case[pre + "res_norm"])) <= 1e-9 * scale
         dn.close()
 
 

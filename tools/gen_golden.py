@@ -50,8 +50,23 @@ def _margin(p, lb, ub):
     return d.min() if d.size else np.inf
 
 
+def _exact_solve(K, rhs):
+    """K^-1 rhs to (nearly) double precision accuracy: LU + refinement with the residual in
+    80-bit extended precision."""
+    import scipy.linalg as sla
+
+    if K.shape[0] == 0:
+        return np.zeros(0)
+    Kl, r = K.astype(np.longdouble), rhs.astype(np.longdouble)
+    lu = sla.lu_factor(K)
+    s = sla.lu_solve(lu, rhs).astype(np.longdouble)
+    for _ in range(6):
+        s = s + sla.lu_solve(lu, (r - Kl @ s).astype(np.float64)).astype(np.longdouble)
+    return s.astype(np.float64)
+
+
 def run_case(name, problem, x0, y0, dt, rho, steps, tau=None, policies=POLICIES,
-             store_problem=None):
+             store_problem=None, hard=False):
     """Drive the reference for each policy and dump everything."""
     n, m = problem.num_vars, problem.num_cons
     out = dict(
@@ -108,6 +123,16 @@ def run_case(name, problem, x0, y0, dt, rho, steps, tau=None, policies=POLICIES,
             out[pre + "K"] = _dense(ss.deriv)
             out[pre + "s"] = ss.solver.solve(rhs)
             Kd = _dense(ss.deriv)
+            if hard:
+                # conditioning of this step's system and the forward error of the REFERENCE's
+                # own solve against an extended-precision refinement: the tolerance a
+                # different (but stable) factorisation can be held to
+                sv = np.linalg.svd(Kd, compute_uv=False)
+                out[pre + "cond"] = float(sv.max() / sv.min()) if sv.size else 1.0
+                sx = _exact_solve(Kd, rhs)
+                out[pre + "s_exact"] = sx
+                out[pre + "ref_err"] = float(
+                    np.max(np.abs(out[pre + "s"] - sx)) / max(1.0, np.max(np.abs(sx)))) if sx.size else 0.0
             out[pre + "n_neg"] = int((np.linalg.eigvalsh(0.5 * (Kd + Kd.T)) < 0).sum()) if Kd.shape[0] else 0
             out[pre + "dx"] = step.dx
             out[pre + "dy"] = step.dy
@@ -117,6 +142,7 @@ def run_case(name, problem, x0, y0, dt, rho, steps, tau=None, policies=POLICIES,
             out[pre + "res_norm"] = np.linalg.norm(ufunc.value_at(step.iterate, rho))
             it = step.iterate
     out["min_mask_margin"] = min_margin
+    out["hard"] = bool(hard)
     assert min_margin > 1e-9, (name, min_margin)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(f"{name}: n={n} m={m} steps={steps} margin={min_margin:.2e}")
@@ -353,6 +379,22 @@ def main():
     run_case("ocp_m40", o3, np.zeros(80), np.zeros(40), 1.0, 1.0, 3, store_problem=qp_store(o3))
     b5 = P.box_qp(256, seed=0)
     run_case("box_qp_n256", b5, np.zeros(256), [], 1.0, 1.0, 6, store_problem=qp_store(b5))
+
+    # ---- outside the easy regime: indefinite H[I,I] + lambda I (n_neg != m) on the
+    # non-convex quartic NLP at large dt, and ill-conditioned dense QPs (cond(K) up to ~3e5 with
+    # element growth > 100 in an unpivoted LDL^T).  Each step also stores cond(K), the
+    # extended-precision solution and the reference's own forward error.
+    run_case("hard_quartic_n40_m12_dt5", qn2, np.zeros(40), np.zeros(12), 5.0, 1.3, 3,
+             store_problem=quartic_store(qn2), hard=True)
+    qn3 = P.quartic_nlp(150, 40, seed=5)
+    run_case("hard_quartic_n150_m40_dt10", qn3, np.clip(np.zeros(150), qn3.var_lb, qn3.var_ub),
+             np.zeros(40), 10.0, 1.0, 2, store_problem=quartic_store(qn3), hard=True)
+    ic1 = P.illcond_qp(200, 56, seed=4, lo=-4.0, hi=4.0)
+    run_case("hard_illcond_n200_m56_dt1e5", ic1, np.zeros(200), np.zeros(56), 1e5, 1.0, 2,
+             store_problem=qp_store(ic1), hard=True)
+    ic2 = P.illcond_qp(200, 56, seed=4, lo=-5.0, hi=4.0)
+    run_case("hard_illcond_n200_m56_dt1e6", ic2, np.zeros(200), np.zeros(56), 1e6, 1.0, 2,
+             store_problem=qp_store(ic2), hard=True)
 
     # the reference's Globalized policy solves at the OUTER iterate (newton.py:248), so its
     # line search only survives one step on the nonlinear problem; three on the QP at dt=0.1
