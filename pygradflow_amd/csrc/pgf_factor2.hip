@@ -527,18 +527,32 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
     // from M, B = X D^-1): the C tiles live in global memory; ALL of a wavefront's tiles are
     // fetched in one burst here, so that their latency (they were last written by another
     // kernel: HBM / Infinity Cache, ~2 us) is paid once and hides behind the write-back.
-    constexpr int MT = 96 / NW;  // 16 x 16 MFMA tiles per wavefront (6 tiles of 64 x 64 at most)
+    // Only 16 x 16 sub-tiles on or below the diagonal are enumerated, dealt round-robin: the
+    // phase is bound by the CU's matrix pipes, every wavefront should carry the same number.
+    constexpr int MT = (78 + NW - 1) / NW;  // sub-tiles per wavefront, at most (78 = 3*10 + 3*16)
     const int nt = ownp / 64;
-    const int total = nt * (nt + 1) / 2 * 16;
+    const int total = nt * (nt + 1) / 2 * 16 - nt * 6;
     auto decode = [&](int e, int &gi, int &gj, int &mi, int &mj) {
-      int T = e >> 4, I = 0;
-      while (T > I) {
-        T -= I + 1;
-        ++I;
+      int I = 0, J = 0;
+      while (true) {  // tile (I, J), J <= I, holds 10 (I == J) or 16 live sub-tiles
+        const int cnt = (I == J) ? 10 : 16;
+        if (e < cnt) break;
+        e -= cnt;
+        if (++J > I) {
+          J = 0;
+          ++I;
+        }
       }
-      const int ti = (e >> 2) & 3, tj = e & 3;
+      int ti, tj;
+      if (I == J) {
+        ti = (e >= 6) ? 3 : (e >= 3) ? 2 : (e >= 1) ? 1 : 0;
+        tj = e - ti * (ti + 1) / 2;
+      } else {
+        ti = e >> 2;
+        tj = e & 3;
+      }
       mi = 64 + 64 * I + 16 * ti;
-      mj = 64 + 64 * T + 16 * tj;
+      mj = 64 + 64 * J + 16 * tj;
       gi = cb + mi;
       gj = cb + mj;
     };
@@ -589,7 +603,7 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
       if (e < total) {
         int gi, gj, mi, mj;
         decode(e, gi, gj, mi, mj);
-        if (gj <= gi + 15) {  // not entirely above the diagonal
+        {
           double4_t c = ct[q];
 #pragma unroll 4
           for (int ks = 0; ks < 64; ks += 4) {
