@@ -247,6 +247,17 @@ int pgf_ls_destroy(pgf_ls_handle ls);
 int pgf_bench_update(int N, int KB, int variant, int reps, int device, double *ms_out,
                      double *flops_out);
 
+/* ---- test hooks ------------------------------------------------------------------ */
+/* The triangular solves of the dense path run as ONE launch whose workgroups hand the
+ * solution over block by block; every such solve checks itself (placement of its workers,
+ * bounded waits).  A failed check never surfaces: the call that notices it repeats the solve
+ * with the per-block kernels before it returns and the chained kernels stay off for the
+ * rest of the process.  pgf_debug_fail_next_chain makes the next chained solve of the
+ * handle look failed (status word set, solution overwritten with NaN) so that the recovery
+ * can be tested; pgf_debug_chain_enable(1) switches the chained kernels back on. */
+int pgf_debug_fail_next_chain(pgf_handle h);
+int pgf_debug_chain_enable(int on);
+
 #ifdef __cplusplus
 }
 #endif

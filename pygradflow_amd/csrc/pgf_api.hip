@@ -50,6 +50,7 @@ struct pgf_solver {
   bool sparse = false;
   PgfProfile prof;
   bool step_pending = false;
+  int last_solve = 0;  // what newton_core_async enqueued: 1 back-solve of row N, 2 full solve
 };
 
 struct pgf_linsolver {
@@ -60,8 +61,8 @@ struct pgf_linsolver {
 };
 
 static const char *k_no_handle = "null handle";
-static const char *k_chain_msg = "chained triangular solve failed its placement / timeout check; "
-                                 "it is switched off now, repeat the call";
+static const char *k_chain_msg = "chained triangular solve failed its placement / timeout check "
+                                 "and so did the per-block solve that replaced it";
 
 static int fail(pgf_handle h, int code, const char *msg) {
   if (h) h->err = msg;
@@ -475,7 +476,38 @@ static int factor_finish(pgf_handle h) {
   const int st = ldlt_finish(h->fac, &e);
   if (st < 0) return hip_fail(h, e, "factor");
   if (st == 1) return fail(h, PGF_SINGULAR, "zero or non-finite pivot in LDL^T of the KKT matrix");
-  if (st == 2) return fail(h, PGF_HIP_ERROR, k_chain_msg);
+  return PGF_OK;
+}
+
+static void enqueue_step_update(pgf_handle h) {
+  launch_step_update(h->stream, h->n, h->m, h->nI, h->fact, h->rho, h->x, h->y, h->lb, h->ub,
+                     h->mask, h->pos, h->b0full, h->F, h->sol, h->dx, h->dy, h->xn, h->yn, h->red,
+                     h->scal);
+}
+
+// After a host synchronisation: a chained triangular solve that failed its own checks
+// (placement, timeout) has left garbage in h->sol and whatever was derived from it.  The
+// chain is off from now on (ldlt_chain_check); the solve and the step update are enqueued
+// again with the per-super-block kernels and awaited, so that the caller never sees the
+// failure.  swapped: the caller has already exchanged (x, y) with (xn, yn) (pgf_qp_step_async).
+static int chain_recover(pgf_handle h, bool swapped) {
+  if (h->sparse || !ldlt_chain_check(h->fac)) return PGF_OK;
+  if (swapped) {
+    std::swap(h->x, h->xn);
+    std::swap(h->y, h->yn);
+  }
+  if (h->last_solve == 1)
+    HIPCHK(h, ldlt_backsolve_async(h->fac, h->fac.K + (int64_t)h->N * h->fac.ldk, h->sol));
+  else
+    HIPCHK(h, ldlt_solve_async(h->fac, h->rhs, h->sol));
+  enqueue_step_update(h);
+  if (swapped) {
+    std::swap(h->x, h->xn);
+    std::swap(h->y, h->yn);
+  }
+  HIPCHK(h, hipMemcpyAsync(h->h_scal, h->scal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (ldlt_chain_check(h->fac)) return fail(h, PGF_HIP_ERROR, k_chain_msg);
   return PGF_OK;
 }
 
@@ -551,13 +583,13 @@ static int newton_core_async(pgf_handle h, bool *did_factor) {
     int rc;
     if ((rc = factor_async(h, true))) return rc;
     *did_factor = true;
+    h->last_solve = 1;
     HIPCHK(h, ldlt_backsolve_async(h->fac, h->fac.K + (int64_t)h->N * h->fac.ldk, h->sol));
   } else {
+    h->last_solve = 2;
     HIPCHK(h, ldlt_solve_async(h->fac, h->rhs, h->sol));
   }
-  launch_step_update(s, h->n, h->m, h->nI, h->fact, h->rho, h->x, h->y, h->lb, h->ub, h->mask,
-                     h->pos, h->b0full, h->F, h->sol, h->dx, h->dy, h->xn, h->yn, h->red,
-                     h->scal);
+  enqueue_step_update(h);
   return PGF_OK;
 }
 
@@ -576,17 +608,19 @@ int pgf_newton_solve(pgf_handle h, const double *x, const double *y, const doubl
   h->eval_fresh = false;
   bool did_factor;
   if ((rc = newton_core_async(h, &did_factor))) return rc;
+  if ((rc = down(h, h->h_scal, h->scal, sizeof(double)))) return rc;
   if (did_factor) {
     if ((rc = factor_finish(h))) return rc;
+  } else {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
   }
+  if ((rc = chain_recover(h, false))) return rc;
   if (inertia_check && h->fac.n_neg != h->m) return fail(h, PGF_INERTIA, "Invalid matrix inertia");
   if (dx && (rc = down(h, dx, h->dx, h->n * sizeof(double)))) return rc;
   if (dy && (rc = down(h, dy, h->dy, h->m * sizeof(double)))) return rc;
   if (xn && (rc = down(h, xn, h->xn, h->n * sizeof(double)))) return rc;
   if (yn && (rc = down(h, yn, h->yn, h->m * sizeof(double)))) return rc;
-  if ((rc = down(h, h->h_scal, h->scal, sizeof(double)))) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (!h->sparse && ldlt_chain_check(h->fac)) return fail(h, PGF_HIP_ERROR, k_chain_msg);
   if (diff) *diff = h->h_scal[0];
   return PGF_OK;
 }
@@ -633,7 +667,12 @@ int pgf_linear_solve(pgf_handle h, const double *rhs, int trans, double *sol) {
   HIPCHK(h, ldlt_solve_async(h->fac, h->rhs, h->sol));
   if ((rc = down(h, sol, h->sol, h->N * sizeof(double)))) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (ldlt_chain_check(h->fac)) return fail(h, PGF_HIP_ERROR, k_chain_msg);
+  if (ldlt_chain_check(h->fac)) {  // the chain is off now: once more with the per-block kernels
+    HIPCHK(h, ldlt_solve_async(h->fac, h->rhs, h->sol));
+    if ((rc = down(h, sol, h->sol, h->N * sizeof(double)))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (ldlt_chain_check(h->fac)) return fail(h, PGF_HIP_ERROR, k_chain_msg);
+  }
   return PGF_OK;
 }
 
@@ -923,9 +962,21 @@ int pgf_qp_sync(pgf_handle h, int *n_neg, double *diff) {
   const int st = ldlt_finish(h->fac, &e);  // flags are only rewritten by a factor launch
   if (st < 0) return hip_fail(h, e, "step");
   if (st == 1) return fail(h, PGF_SINGULAR, "zero or non-finite pivot in LDL^T of the KKT matrix");
-  if (st == 2) return fail(h, PGF_HIP_ERROR, k_chain_msg);
+  int rc;
+  if ((rc = chain_recover(h, true))) return rc;
   if (n_neg) *n_neg = h->fac.n_neg;
   if (diff) *diff = h->h_scal[0];
+  return PGF_OK;
+}
+
+int pgf_debug_fail_next_chain(pgf_handle h) {
+  if (!h) return PGF_INVALID;
+  h->fac.inject_chain_failure = 1;
+  return PGF_OK;
+}
+
+int pgf_debug_chain_enable(int on) {
+  ldlt_chain_set_enabled(on != 0);
   return PGF_OK;
 }
 
@@ -1489,7 +1540,13 @@ int pgf_ls_solve(pgf_ls_handle ls, const double *rhs, int trans, double *sol) {
   if (e == hipSuccess)
     e = hipMemcpyAsync(sol, ls->sol, ls->N * sizeof(double), hipMemcpyDeviceToHost, ls->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ls->stream);
-  if (e == hipSuccess && ldlt_chain_check(ls->fac)) return PGF_HIP_ERROR;
+  if (e == hipSuccess && ldlt_chain_check(ls->fac)) {  // chain off now: per-block kernels
+    e = ldlt_solve_async(ls->fac, ls->rhs, ls->sol);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(sol, ls->sol, ls->N * sizeof(double), hipMemcpyDeviceToHost, ls->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ls->stream);
+    if (e == hipSuccess && ldlt_chain_check(ls->fac)) return PGF_HIP_ERROR;
+  }
   return e == hipSuccess ? PGF_OK : PGF_HIP_ERROR + (int)e;
 }
 

@@ -45,14 +45,15 @@ struct DenseLdlt {
   bool factored = false;
   int n_neg = 0;
   PgfProfile *prof = nullptr;
+  int inject_chain_failure = 0;  // test hook: the next chained solve reports a failure
 };
 
 hipError_t ldlt_alloc(DenseLdlt &f, int Nmax, hipStream_t stream);
 void ldlt_free(DenseLdlt &f);
 // enqueue the factorisation of the leading N x N lower triangle (+ rows up to nrows)
 hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows);
-// wait and read flags: returns 0 ok / 1 singular / 2 a chained solve failed its own checks;
-// sets f.n_neg
+// wait and read flags: returns 0 ok / 1 singular; sets f.n_neg.  (A chained solve that failed
+// its own checks is reported by ldlt_chain_check after any host synchronisation.)
 int ldlt_finish(DenseLdlt &f, hipError_t *err);
 // sol <- K^{-1} rhs on device vectors of length N (rhs preserved if rhs != sol)
 hipError_t ldlt_solve_async(DenseLdlt &f, const double *rhs, double *sol);
@@ -60,6 +61,7 @@ hipError_t ldlt_solve_async(DenseLdlt &f, const double *rhs, double *sol);
 hipError_t ldlt_backsolve_async(DenseLdlt &f, const double *w, double *sol);
 // after a host sync: nonzero if a chained solve reported a timeout / placement problem
 int ldlt_chain_check(DenseLdlt &f);
+void ldlt_chain_set_enabled(bool on);  // test hook: undo the switch-off of a failed check
 // look-ahead schedule (pgf_factor2.hip): the default; PGF_FACTOR=1 selects the round-1 one
 bool ldlt_use_lookahead();
 hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows);

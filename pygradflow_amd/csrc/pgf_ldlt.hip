@@ -1349,8 +1349,7 @@ int ldlt_finish(DenseLdlt &f, hipError_t *err) {
   f.n_neg = f.h_flags[1];
   f.factored = (f.h_flags[0] == 0);
   ldlt_chain_timing_dump();  // no-op unless PGF_CHAIN_TIMING is set
-  if (f.h_flags[0]) return 1;
-  return ldlt_chain_check(f) ? 2 : 0;
+  return f.h_flags[0] ? 1 : 0;
 }
 
 // PGF_TRSV_CHAIN=0: one launch per 256-row super-block (the earlier scheme) instead of the
@@ -1361,6 +1360,8 @@ static bool use_chain() {
   static const bool on = !(getenv("PGF_TRSV_CHAIN") && atoi(getenv("PGF_TRSV_CHAIN")) == 0);
   return on && !g_chain_off;
 }
+
+void ldlt_chain_set_enabled(bool on) { g_chain_off = !on; }
 
 // after a host synchronisation of f.stream: did a chained solve since the last check fail its
 // own checks?  (bit 0: a wait timed out, bit 1: workers on different XCDs)
@@ -1374,7 +1375,20 @@ int ldlt_chain_check(DenseLdlt &f) {
   return bad;
 }
 
-static hipError_t chain_report(DenseLdlt &f) {
+// test hook (pgf_debug_fail_next_chain): make the chained solve just enqueued look like one that
+// failed its checks -- status word set, solution overwritten with NaN
+__global__ void k_chain_inject(double *__restrict__ sol, int N, int *__restrict__ ctl) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) sol[i] = __builtin_nan("");
+  if (i == 0) atomicOr(&ctl[1], 1);
+}
+
+static hipError_t chain_report(DenseLdlt &f, double *sol) {
+  if (f.inject_chain_failure) {
+    f.inject_chain_failure = 0;
+    hipLaunchKernelGGL(k_chain_inject, dim3((f.N + 255) / 256), dim3(256), 0, f.stream, sol, f.N,
+                       f.chain + 2 * f.chain_stride);
+  }
   return hipMemcpyAsync(f.h_flags + 3, f.chain + 2 * f.chain_stride + 1, sizeof(int),
                         hipMemcpyDeviceToHost, f.stream);
 }
@@ -1387,7 +1401,7 @@ hipError_t ldlt_backsolve_async(DenseLdlt &f, const double *w, double *sol) {
     const int nblk = (N + 63) / 64;
     hipLaunchKernelGGL(k_trsv_bwd_chain, dim3(8 * nblk), dim3(256), 0, s, f.K, f.ldk, f.Linv, w, sol,
                        N, f.chain, ++f.chain_epoch, f.chain + 2 * f.chain_stride);
-    return chain_report(f);
+    return chain_report(f, sol);
   }
   hipLaunchKernelGGL(k_vec_copy_strided, dim3((N + 255) / 256), dim3(256), 0, s, f.zwork, w, N);
   constexpr int SUPER = 256;

@@ -384,6 +384,12 @@ class HipStepSolver:
             _lib.check(self._lib.pgf_get_kkt(self._hd.h, _lib.dptr(K), N), self._hd.h, "pgf_get_kkt")
         return K
 
+    def solver_for_tests(self):
+        """``LinearSolver`` view of the device factor without taking a step (parity tests:
+        the factorisation is triggered by the first ``solve`` / ``num_neg_eigvals``)."""
+        self._push_state()
+        return _DeviceFactorView(self)
+
     # -- the step (scaled_step_solver.py:85-107) ---------------------------
     def solve(self, iterate):
         params = self.params

@@ -540,3 +540,181 @@ def test_device_batch_edge_sizes(pgf):
             assert mk[1].all()  # the all-active instance really occurred
         bd.close()
         ref.close()
+
+
+# ------------------------------------------------------------------ round-2 additions
+@pytest.mark.parametrize("B", [9, 17, 32])
+def test_device_batch_shard_against_oracle(pgf, B):
+    """One rank's shard of BASELINE config 4 (32 instances of n=1024, m=256 per GPU at 8 GPUs;
+    9 and 17 leave the XCD residue classes unevenly filled): with more than 8 instances the
+    workgroup -> (instance, tile) decode walks several instances per XCD.  EVERY instance is
+    checked against the CPU restatement: 2 Full steps, then -- on the same outer step -- one
+    ActiveSet step and one Simplified step through the per-instance drivers' policies."""
+    from pygradflow_amd import problems
+    from pygradflow_amd.batched import BatchedDeviceNewton
+
+    n, m = 1024, 256
+
+    def make(i):
+        return problems.dense_qp(n, m, seed=i, boxed_frac=0.05 * (i % 7), box=0.02)
+
+    for kind, steps in (("Full", 2), ("ActiveSet", 1), ("Simplified", 1)):
+        bd = BatchedDeviceNewton(make, B, kind, 1.0, 1.0)
+        ors = [O.NewtonOracle(make(i), kind, np.zeros(n), np.zeros(m), 1.0, 1.0) for i in range(B)]
+        pts = [(np.zeros(n), np.zeros(m)) for _ in range(B)]
+        sizes = set()
+        for k in range(steps):
+            st, nn, df = bd.step_local()
+            assert not st.any() and (nn == m).all()
+            x, y = bd.points()
+            mk = bd.masks()
+            for i in range(B):
+                xn, yn, _ = ors[i].step(*pts[i])
+                pts[i] = (xn, yn)
+                assert np.array_equal(mk[i], ors[i].solver.record["mask"]), (kind, k, i)
+                assert G.rel_err(x[i], xn) <= TOL and G.rel_err(y[i], yn) <= TOL, (kind, k, i)
+                sizes.add(int(n - mk[i].sum()))
+        assert len(sizes) > 1  # the instances really had different reduced sizes
+        bd.close()
+
+
+def _indefinite_problem():
+    """Tiny QP whose Hessian has a negative eigenvalue larger than lambda = 1 / dt: the reduced
+    KKT matrix has m + 1 negative eigenvalues."""
+    from pygradflow_amd import problems
+
+    Q = np.diag([-3.0, 2.0, 1.0, 4.0])
+    A = np.array([[1.0, 1.0, 0.0, 0.0]])
+    return problems.LinearQuadraticProblem(Q, np.ones(4), A, np.zeros(1), np.full(4, -np.inf),
+                                           np.full(4, np.inf))
+
+
+def test_inertia_correction_raises_step_solver_error(pgf):
+    """Params.inertia_correction: a wrong inertia is a LinearSolverError('Invalid matrix
+    inertia') in the reference (symmetric_step_solver.py:146-153), re-raised as
+    StepSolverError (:155-156).  Without the flag the same step goes through."""
+    prob = _indefinite_problem()
+    for flag in (False, True):
+        params = pgf.Params(newton_type="Full", inertia_correction=flag)
+        it = pgf.Iterate(prob, params, np.zeros(4), np.zeros(1))
+        sv = pgf.HipStepSolver(prob, params, it, 1.0, 1.0)
+        sv.update_active_set(np.zeros(4, dtype=bool))
+        sv.update_derivs(it)
+        if flag:
+            with pytest.raises(pgf.StepSolverError, match="inertia"):
+                sv.solve(it)
+        else:
+            res = sv.solve(it)
+            assert sv.solver.num_neg_eigvals() == 2 and np.isfinite(res.dx).all()
+        sv.close()
+    # the device-resident driver reports the same condition
+    dn = pgf.DeviceNewton(prob, "Full", np.zeros(4), np.zeros(1), 1.0, 1.0)
+    with pytest.raises(pgf.StepSolverError, match="inertia"):
+        dn.step(inertia_check=True)
+    dn.close()
+
+
+def test_singular_kkt_raises_step_solver_error_and_controller_rejects(pgf):
+    """A singular reduced KKT matrix (H + lambda I has an exactly zero pivot): the factorisation
+    reports it, HipStepSolver.solve raises StepSolverError (symmetric_step_solver.py:155-156)
+    and StepController.compute_step turns that into a rejected step with doubled lambda
+    (step/step_control.py:80-107)."""
+    from pygradflow_amd import problems
+    from pygradflow_amd.step_control import DistanceRatioController
+
+    Q = np.diag([-1.0, 2.0, 3.0])
+    prob = problems.LinearQuadraticProblem(Q, np.ones(3), np.zeros((0, 3)), np.zeros(0),
+                                           np.full(3, -np.inf), np.full(3, np.inf))
+    params = pgf.Params(newton_type="Full", step_solver=pgf.HipStepSolver)
+    it = pgf.Iterate(prob, params, np.zeros(3), np.zeros(0))
+    sv = pgf.HipStepSolver(prob, params, it, 1.0, 1.0)  # lambda = 1: first pivot -1 + 1 = 0
+    sv.update_active_set(np.zeros(3, dtype=bool))
+    sv.update_derivs(it)
+    with pytest.raises(pgf.StepSolverError):
+        sv.solve(it)
+    sv.close()
+    res = DistanceRatioController(prob, params).compute_step(it, 1.0, 1.0)
+    assert not res.accepted and res.lamb == 2.0
+
+
+def test_chain_failure_is_recovered_inside_the_call(pgf):
+    """A chained triangular solve that fails its own checks must not surface: the
+    call repeats the solve with the per-block kernels before it touches the point.  The test
+    hook marks the next chained solve as failed and overwrites its solution with NaN."""
+    import ctypes as C
+
+    from pygradflow_amd import _lib, problems
+
+    lib = _lib.load()
+    n, m = 300, 80
+    prob = problems.dense_qp(n, m, seed=3, boxed_frac=0.2, box=0.05)
+    ref = pgf.DeviceNewton(prob, "Full", np.zeros(n), np.zeros(m), 1.0, 1.0)
+    dn = pgf.DeviceNewton(problems.dense_qp(n, m, seed=3, boxed_frac=0.2, box=0.05), "Full",
+                          np.zeros(n), np.zeros(m), 1.0, 1.0)
+    try:
+        for k in range(3):
+            d0, _ = ref.step()
+            if k == 1:
+                _lib.check(lib.pgf_debug_fail_next_chain(dn._hd.h))
+            d1, _ = dn.step()
+            x0, y0 = ref.point()
+            x1, y1 = dn.point()
+            assert np.isfinite(x1).all() and np.isfinite(y1).all()
+            assert G.rel_err(x1, x0) <= 1e-12 and G.rel_err(y1, y0) <= 1e-12, k
+            assert abs(d0 - d1) <= 1e-12 * max(1.0, d0)
+        # plugin path: the same through pgf_newton_solve / pgf_linear_solve
+        params = pgf.Params(newton_type="Full")
+        it = pgf.Iterate(prob, params, np.zeros(n), np.zeros(m))
+        sv = pgf.HipStepSolver(prob, params, it, 1.0, 1.0)
+        sv.update_active_set(sv.func.compute_active_set(it, 1.0))
+        sv.update_derivs(it)
+        good = sv.solve(it)
+        lib.pgf_debug_chain_enable(1)
+        _lib.check(lib.pgf_debug_fail_next_chain(sv._hd.h))
+        again = sv.solve(it)  # factor still valid: forward + backward chained solves
+        assert np.array_equal(good.dx, again.dx) or G.rel_err(again.dx, good.dx) <= 1e-12
+        rhs = np.arange(1.0, sv.reduced_dims()[1] + 1.0)
+        s0 = sv.solver.solve(rhs)
+        lib.pgf_debug_chain_enable(1)
+        _lib.check(lib.pgf_debug_fail_next_chain(sv._hd.h))
+        s1 = sv.solver.solve(rhs)
+        assert np.isfinite(s1).all() and G.rel_err(s1, s0) <= 1e-12
+        sv.close()
+    finally:
+        lib.pgf_debug_chain_enable(1)
+        ref.close()
+        dn.close()
+
+
+@pytest.mark.parametrize("name", [n for n in G.case_names() if n.startswith("hard_")])
+def test_hard_regime_accuracy_against_exact_solution(pgf, name):
+    """Outside the quasi-definite comfort zone (indefinite H[I,I] + lambda I: n_neg != m;
+    cond(K) up to 3e5 with element growth > 100 in an unpivoted LDL^T): the linear solve of
+    every recorded step is compared with the extended-precision solution stored in the
+    fixture, and must be as accurate as the reference's own LU was (its error is stored too),
+    with 1e-10 as the floor."""
+    case = G.load_case(name)
+    shape = G.shape_only_problem(case)
+    dt, rho = float(case["dt"]), float(case["rho"])
+    params = pgf.Params()
+    seen_indefinite = False
+    for pol in case["policies"]:
+        for k in range(int(case["steps"])):
+            pre = f"{pol}/{k}/"
+            orig = G.RecordedPoint(case, pol, 0, shape, params)
+            orig.x, orig.y = case["x0"], case["y0"]
+            sv = pgf.HipStepSolver(shape, params, orig, dt, rho)
+            sv.update_active_set(case[pre + "mask"])
+            frozen = G.RecordedPoint(case, pol, k, shape, params)
+            _, Jf = G.step_derivs(case, pol, k)
+            frozen.jac = frozen.cons_jac = sps.csr_matrix(Jf.reshape(int(case["m"]), int(case["n"])))
+            sv.update_derivs(frozen)
+            s = sv.solver_for_tests().solve(case[pre + "rhs"])
+            exact = case[pre + "s_exact"]
+            tol = max(1e-10, 4.0 * float(case[pre + "ref_err"]))
+            assert G.rel_err(s, exact) <= tol, (pol, k, G.rel_err(s, exact), tol)
+            assert sv.solver_for_tests().num_neg_eigvals() == int(case[pre + "n_neg"])
+            seen_indefinite |= int(case[pre + "n_neg"]) != int(case["m"])
+            sv.close()
+    if "quartic" in name:
+        assert seen_indefinite
