@@ -92,13 +92,15 @@ def pmc_traffic(kernel):
         return None
 
 
-def bench_batched(args, wl, rank, local_rank, world, dist, torch):
+def bench_batched(args, wl, rank, local_rank, world, dist, torch, emit=True, steps=None, warmup=None):
     """BASELINE configs[3]: B independent instances, contiguous shards per rank; every rank
     advances its shard as ONE device batch (pgf_batch_*), one all-gather of norms per step."""
     from pygradflow_amd import problems
     from pygradflow_amd.batched import BatchedDeviceNewton
 
     n, m, B = wl["n"], wl["m"], wl["batch"]
+    nsteps = args.steps if steps is None else steps
+    nwarm = args.warmup if warmup is None else warmup
     bd = BatchedDeviceNewton(lambda i: problems.dense_qp(n, m, seed=i), B, "Full", 1.0, 1.0,
                              device=local_rank, rank=rank, world=world)
     dev = torch.device("cuda", local_rank)
@@ -116,25 +118,44 @@ def bench_batched(args, wl, rank, local_rank, world, dist, torch):
 
     # parity of instance 0's first step against the CPU restatement (rank 0, bounded)
     parity = cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and emit:
         rate, recs, csteps, cel = cpu_baseline(problems.dense_qp(n, m, seed=0), args.cpu_seconds)
         bd.step_local()
         xg, yg = bd.points()
-        r0 = recs[0]
+        mk = bd.masks()
         rel = lambda a, b: float(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b)))) if b.size else 0.0
-        parity = dict(instance=0,
-                      mask_hamming=int(np.count_nonzero(bd.masks()[0] != r0["mask"])),
-                      iterate_rel_err=max(rel(xg[0], r0["xn"]), rel(yg[0], r0["yn"])))
+        # every local instance's mask and the iterates of 8 of them against the CPU restatement
+        from oracle import newton_oracle as O
+        sample = sorted(set(np.linspace(0, bd.hi - bd.lo - 1, 8).astype(int).tolist()))
+        ham, worst = 0, 0.0
+        for i in range(bd.hi - bd.lo):
+            pi = problems.dense_qp(n, m, seed=bd.lo + i)
+            if i == 0:
+                ri = recs[0]
+            elif i in sample:
+                orc = O.NewtonOracle(pi, "Full", np.zeros(n), np.zeros(m), 1.0, 1.0)
+                orc.step(np.zeros(n), np.zeros(m))
+                ri = orc.solver.record
+            else:
+                # unbounded variables: the reference's mask is empty whatever the point
+                ri = dict(mask=np.zeros(n, dtype=bool)) if not pi.var_bounded else None
+            if ri is None:
+                continue
+            ham += int(np.count_nonzero(mk[i] != ri["mask"]))
+            if "xn" in ri:
+                worst = max(worst, rel(xg[i], ri["xn"]), rel(yg[i], ri["yn"]))
+        parity = dict(instances_masks_checked=bd.hi - bd.lo, instances_iterates_checked=len(sample),
+                      mask_hamming=ham, iterate_rel_err=worst)
         cpu = dict(value=rate, unit="instance Newton steps/s", cores=1, kind="port",
                    sample=f"{csteps} Full Newton step(s) of ONE n={n} m={m} instance from x0=y0=0 "
                           f"(scipy bmat + SuperLU splu as the reference calls them; the "
                           f"reference runs instances in a process pool, so scale by the cores "
                           f"used), {cel:.1f} s; host has {os.cpu_count()} cores")
-    for i in range(args.warmup):
+    for i in range(nwarm):
         one_step(i)
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(nsteps):
         norms = one_step(i)
     fence()
     elapsed = time.perf_counter() - t0
@@ -146,7 +167,7 @@ def bench_batched(args, wl, rank, local_rank, world, dist, torch):
     roof = None
     if rank == 0:
         bd.profile(True)
-    for i in range(args.steps):
+    for i in range(nsteps):
         one_step(i)
     if rank == 0:
         pr = bd.profile_read()
@@ -156,25 +177,34 @@ def bench_batched(args, wl, rank, local_rank, world, dist, torch):
             roof = dict(bound="mfma", kernel="kb_ldlt_update", achieved=achieved,
                         peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s",
                         frac=achieved / PEAK_FP64_MFMA_TFLOPS, traffic=pmc_traffic("kb_ldlt_update"),
-                        launches_per_step=pr["update_launches"] / args.steps,
+                        launches_per_step=pr["update_launches"] / nsteps,
                         avg_launch_us=1e3 * pr["update_ms"] / pr["update_launches"],
-                        flops_per_step=pr["update_flops"] / args.steps,
+                        flops_per_step=pr["update_flops"] / nsteps,
                         step_flops=(bd.hi - bd.lo) * ((n + m) ** 3 / 3.0 + 2.0 * (n + m) ** 2))
+            # step level: 1.80e11 flop per batched step over all ranks
+            sf = B * ((n + m) ** 3 / 3.0 + 2.0 * (n + m) ** 2 + 2.0 * n * n + 4.0 * n * m)
+            roof["step_achieved"] = sf * (nsteps / elapsed) / 1e12
+            roof["step_frac"] = roof["step_achieved"] / (PEAK_FP64_MFMA_TFLOPS * world)
+    record = None
     if rank == 0:
         assert norms.numel() == B
-        print(json.dumps({
+        record = {
             "metric": "Newton steps/sec on dense KKT n=1024 m=256, batch of 256 instances",
-            "value": args.steps * B / elapsed, "unit": "instance Newton steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "value": nsteps * B / elapsed, "unit": "instance Newton steps/s",
+            "n_gpus": world, "steps": nsteps, "warmup": nwarm,
+            "ms_per_step": 1e3 * elapsed / nsteps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": args.workload, "n": n, "m": m, "instances": B,
+            "config": {"workload": "batch256_n1024_m256", "n": n, "m": m, "instances": B,
                        "instances_per_gpu": bd.hi - bd.lo, "newton_type": "Full",
                        "path": "device batch (pgf_batch_*, instance = XCD-pinned workgroup range)",
                        "collective": "all_gather(256 residual norms)" if world > 1 else "none"},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
-        }), flush=True)
+        }
     bd.close()
+    if not emit:
+        return record
+    if rank == 0:
+        print(json.dumps(record), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -289,16 +319,29 @@ def main():
 
                 Kd = r0["K"].toarray() if hasattr(r0["K"], "toarray") else np.asarray(r0["K"])
                 rhs_d = np.asarray(r0["rhs"], dtype=np.float64)
-                sla.lu_solve(sla.lu_factor(Kd), rhs_d)  # warm up the BLAS threads
-                reps, tl = 0, time.perf_counter()
-                while reps < 5 and time.perf_counter() - tl < 10.0:
-                    sla.lu_solve(sla.lu_factor(Kd), rhs_d)
-                    reps += 1
-                dense_s = (time.perf_counter() - tl) / reps
+                # pinned thread count: with every hardware thread of a 256-core host the LU of
+                # a 5120^2 matrix is oversubscribed (53 GFLOP/s in round 1); 16 threads = the
+                # CPU share of one GPU on the bench box
+                nthr = min(16, os.cpu_count() or 1)
+                import contextlib
+
+                try:
+                    from threadpoolctl import threadpool_limits
+                    limiter = threadpool_limits(limits=nthr, user_api="blas")
+                except Exception:
+                    limiter, nthr = contextlib.nullcontext(), os.cpu_count()
+                with limiter:
+                    sla.lu_solve(sla.lu_factor(Kd), rhs_d)  # warm up the BLAS threads
+                    reps, tl = 0, time.perf_counter()
+                    while reps < 5 and time.perf_counter() - tl < 10.0:
+                        sla.lu_solve(sla.lu_factor(Kd), rhs_d)
+                        reps += 1
+                    dense_s = (time.perf_counter() - tl) / reps
                 cpu["dense_lapack"] = dict(
-                    value=1.0 / dense_s, unit="factor+solve/s", cores=os.cpu_count(),
+                    value=1.0 / dense_s, unit="factor+solve/s", cores=nthr,
+                    gflops=(2.0 / 3.0 * Kd.shape[0] ** 3) / dense_s / 1e9,
                     sample=f"{reps} x scipy.linalg.lu_factor + lu_solve of the {Kd.shape[0]}^2 KKT "
-                           f"matrix of step 1 (all BLAS threads), {1e3 * dense_s:.1f} ms each")
+                           f"matrix of step 1 ({nthr} BLAS threads), {1e3 * dense_s:.1f} ms each")
                 del Kd
             except Exception as e:  # the port number above stays valid without this extra
                 cpu["dense_lapack"] = dict(value=None, error=str(e)[:200])
@@ -354,16 +397,42 @@ def main():
                              "launch/latency-bound, not bandwidth-bound, at this size")
         elif pr["update_launches"] > 0 and pr["update_ms"] > 0:
             achieved = pr["update_flops"] / (pr["update_ms"] * 1e-3) / 1e12
+            traffic = (pmc_traffic("k_ldlt_update")
+                       if args.workload == "dense_qp_n4096_m1024" else None)
+            alg_bytes = pr["update_bytes"] / pr["update_launches"]
             roof = dict(
                 bound="mfma", kernel="k_ldlt_update", achieved=achieved,
                 peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP64_MFMA_TFLOPS,
-                traffic=(pmc_traffic("k_ldlt_update")
-                         if args.workload == "dense_qp_n4096_m1024" else None),
+                traffic=traffic,
+                algorithmic_bytes_per_launch=alg_bytes,
+                traffic_over_algorithmic=(traffic / alg_bytes) if traffic else None,
                 launches_per_step=pr["update_launches"] / args.steps,
                 avg_launch_us=1e3 * pr["update_ms"] / pr["update_launches"],
                 flops_per_step=pr["update_flops"] / args.steps,
                 factor_ms_per_step=pr["factor_ms"] / args.steps,
+                note=("per-kernel figures from an instrumented pass over the same steps in which "
+                      "the factorisation's kernels run as separate launches with HIP events "
+                      "around them; in the timed region the diagonal chain and the trailing "
+                      "update share one launch (k_chain_update)"),
             )
+            # the STEP against the FP64-MFMA roof -- algorithmic flops of one
+            # Full Newton step (factor N^3/3, solves 2 N^2, residual 2 n^2 + 4 n m) x steps/s
+            N_ = n + m
+            step_flops = N_ ** 3 / 3.0 + 2.0 * N_ ** 2 + 2.0 * n * n + 4.0 * n * m
+            roof["step_flops"] = step_flops
+            roof["step_achieved"] = step_flops * (args.steps / elapsed) / 1e12
+            roof["step_frac"] = roof["step_achieved"] / PEAK_FP64_MFMA_TFLOPS
+            # where the step's time goes (instrumented pass, ms per step)
+            parts = {"k_diag_chain": pr["chain_ms"], "k_ldlt_update": pr["update_ms"],
+                     "k_trsm_block": pr["trsm_ms"], "k_update_diag": pr["udiag_ms"]}
+            dom = max(parts, key=parts.get)
+            roof["time_dominant_kernel"] = dict(
+                kernel=dom, ms_per_step=parts[dom] / args.steps,
+                launches_per_step=(pr["chain_launches"] / args.steps if dom == "k_diag_chain" else None),
+                note=("the factorisation's serial pivot chain: ONE workgroup per 256-column "
+                      "block; in the production schedule it runs beside the previous block's "
+                      "k_ldlt_update inside one launch" if dom == "k_diag_chain" else None))
+            roof["kernel_ms_per_step"] = {k: v / args.steps for k, v in parts.items()}
 
     # SURVEY.md 8d "reported separately": the back-solve step of the Simplified policy
     # (2nd+ Newton step of an outer iteration: residual, reduced rhs, forward + backward
@@ -385,6 +454,15 @@ def main():
         backsolve = dict(ms_per_step=bms, steps_per_s=1e3 / bms, steps=nbs)
         dn = ds
 
+    # BASELINE configs[3] (what north_star names for multi-GPU scaling): at N > 1 the same
+    # launch also times the 256-instance batch, 256 / N instances per rank, one all-gather of
+    # 256 residual norms per batched step -- a nested record, strong scaling over N
+    batch_rec = None
+    if world > 1 and args.workload == "dense_qp_n4096_m1024":
+        dn.close()
+        batch_rec = bench_batched(args, WORKLOADS["batch256_n1024_m256"], rank, local_rank, world,
+                                  dist, torch, emit=False, steps=min(args.steps, 8), warmup=2)
+        dn = None
     if rank == 0:
         total_steps = args.steps * world
         out = {
@@ -410,9 +488,11 @@ def main():
             "cpu_baseline": cpu,
             "parity": parity,
             "backsolve_step": backsolve,
+            "batch256": batch_rec,
         }
         print(json.dumps(out), flush=True)
-    dn.close()
+    if dn is not None:
+        dn.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -181,6 +181,23 @@ int pgf_stream(pgf_handle h, void **stream_out);
 int pgf_profile_enable(pgf_handle h, int on);
 int pgf_profile_read(pgf_handle h, double *update_ms, int64_t *update_launches,
                      double *update_flops, double *factor_ms);
+/* the same and more, as one array (count >= PGF_PROF_COUNT).  While profiling is enabled the
+ * dense factorisation runs its kernels as separate launches (the production schedule fuses
+ * the diagonal chain with the trailing update in one launch) so that each can be timed:
+ * update (k_ldlt_update) ms / launches / algorithmic flops / algorithmic bytes, whole
+ * factorisation ms, diagonal chain (k_diag_chain) ms / launches, TRSM below the diagonal
+ * block (k_trsm_block) ms, diagonal-block update (k_update_diag) ms */
+#define PGF_PROF_UPDATE_MS 0
+#define PGF_PROF_UPDATE_LAUNCHES 1
+#define PGF_PROF_UPDATE_FLOPS 2
+#define PGF_PROF_UPDATE_BYTES 3
+#define PGF_PROF_FACTOR_MS 4
+#define PGF_PROF_CHAIN_MS 5
+#define PGF_PROF_CHAIN_LAUNCHES 6
+#define PGF_PROF_TRSM_MS 7
+#define PGF_PROF_UDIAG_MS 8
+#define PGF_PROF_COUNT 9
+int pgf_profile_read_ex(pgf_handle h, double *out, int count);
 
 /* ---- batched mode: many device-resident instances advanced by ONE launch sequence ---- */
 /* The reference's only parallelism is a process pool over independent instances

@@ -90,6 +90,7 @@ SIGNATURES = {
     "pgf_ls_get_factor": (C.c_int, [_h, _dp, C.c_int64]),
     "pgf_ls_destroy": (C.c_int, [_h]),
     "pgf_bench_update": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]),
+    "pgf_profile_read_ex": (C.c_int, [_h, _dp, C.c_int]),
     "pgf_debug_fail_next_chain": (C.c_int, [_h]),
     "pgf_debug_chain_enable": (C.c_int, [C.c_int]),
 }

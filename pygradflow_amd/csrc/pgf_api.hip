@@ -1459,36 +1459,73 @@ int pgf_profile_enable(pgf_handle h, int on) {
   return PGF_OK;
 }
 
-int pgf_profile_read(pgf_handle h, double *update_ms, int64_t *update_launches,
-                     double *update_flops, double *factor_ms) {
-  if (!h) return PGF_INVALID;
-  (void)hipSetDevice(h->device);
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  PgfProfile &p = h->prof;
+static void profile_collect(PgfProfile &p) {
   for (size_t i = 0; i < p.update_spans.size(); ++i) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, p.update_spans[i].first, p.update_spans[i].second) == hipSuccess)
       p.acc_update_ms += ms;
     p.acc_update_flops += p.update_flops[i];
+    if (i < p.update_bytes.size()) p.acc_update_bytes += p.update_bytes[i];
     p.acc_update_launches += 1;
     p.pool.push_back(p.update_spans[i].first);
     p.pool.push_back(p.update_spans[i].second);
   }
   p.update_spans.clear();
   p.update_flops.clear();
-  for (auto &sp : p.factor_spans) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, sp.first, sp.second) == hipSuccess) p.acc_factor_ms += ms;
-    p.pool.push_back(sp.first);
-    p.pool.push_back(sp.second);
-  }
-  p.factor_spans.clear();
+  p.update_bytes.clear();
+  auto drain = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double &acc, int64_t *cnt) {
+    for (auto &sp : v) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, sp.first, sp.second) == hipSuccess) acc += ms;
+      if (cnt) *cnt += 1;
+      p.pool.push_back(sp.first);
+      p.pool.push_back(sp.second);
+    }
+    v.clear();
+  };
+  drain(p.factor_spans, p.acc_factor_ms, nullptr);
+  drain(p.chain_spans, p.acc_chain_ms, &p.acc_chain_launches);
+  drain(p.trsm_spans, p.acc_trsm_ms, nullptr);
+  drain(p.udiag_spans, p.acc_udiag_ms, nullptr);
+}
+
+static void profile_reset(PgfProfile &p) {
+  p.acc_update_ms = p.acc_update_flops = p.acc_update_bytes = p.acc_factor_ms = 0;
+  p.acc_chain_ms = p.acc_trsm_ms = p.acc_udiag_ms = 0;
+  p.acc_update_launches = p.acc_chain_launches = 0;
+}
+
+int pgf_profile_read(pgf_handle h, double *update_ms, int64_t *update_launches,
+                     double *update_flops, double *factor_ms) {
+  if (!h) return PGF_INVALID;
+  (void)hipSetDevice(h->device);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  PgfProfile &p = h->prof;
+  profile_collect(p);
   if (update_ms) *update_ms = p.acc_update_ms;
   if (update_launches) *update_launches = p.acc_update_launches;
   if (update_flops) *update_flops = p.acc_update_flops;
   if (factor_ms) *factor_ms = p.acc_factor_ms;
-  p.acc_update_ms = p.acc_update_flops = p.acc_factor_ms = 0;
-  p.acc_update_launches = 0;
+  profile_reset(p);
+  return PGF_OK;
+}
+
+int pgf_profile_read_ex(pgf_handle h, double *out, int count) {
+  if (!h || !out || count < PGF_PROF_COUNT) return PGF_INVALID;
+  (void)hipSetDevice(h->device);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  PgfProfile &p = h->prof;
+  profile_collect(p);
+  out[PGF_PROF_UPDATE_MS] = p.acc_update_ms;
+  out[PGF_PROF_UPDATE_LAUNCHES] = (double)p.acc_update_launches;
+  out[PGF_PROF_UPDATE_FLOPS] = p.acc_update_flops;
+  out[PGF_PROF_UPDATE_BYTES] = p.acc_update_bytes;
+  out[PGF_PROF_FACTOR_MS] = p.acc_factor_ms;
+  out[PGF_PROF_CHAIN_MS] = p.acc_chain_ms;
+  out[PGF_PROF_CHAIN_LAUNCHES] = (double)p.acc_chain_launches;
+  out[PGF_PROF_TRSM_MS] = p.acc_trsm_ms;
+  out[PGF_PROF_UDIAG_MS] = p.acc_udiag_ms;
+  profile_reset(p);
   return PGF_OK;
 }
 

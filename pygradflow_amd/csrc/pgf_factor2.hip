@@ -808,7 +808,18 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
   }
   constexpr int OB = 256;
   const int64_t ldw = OB;
+  auto span_begin = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &v) {
+    if (!p) return;
+    v.emplace_back(prof_event(p), prof_event(p));
+    (void)hipEventRecord(v.back().first, s);
+  };
+  auto span_end = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &v) {
+    if (p) (void)hipEventRecord(v.back().second, s);
+  };
+  PgfProfile dummy;
+  PgfProfile &pr = p ? *p : dummy;
   auto launch_d = [&](int c0) {
+    span_begin(pr.chain_spans);
     long long *dbg = (c0 == 0) ? chain_dbg_buffer() : nullptr;
     if (chain_waves() == 16)
       hipLaunchKernelGGL(k_diag_chain<16>, dim3(1), dim3(1024), 0, s, f.K, f.ldk, c0,
@@ -816,13 +827,17 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
     else
       hipLaunchKernelGGL(k_diag_chain<8>, dim3(1), dim3(512), 0, s, f.K, f.ldk, c0,
                          std::min(OB, N - c0), f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, dbg);
+    span_end(pr.chain_spans);
   };
   auto launch_t = [&](int c0, double *Wb) {
     const int nb = std::min(OB, N - c0);
     const int below = nrows - (c0 + nb);
-    if (below > 0)
+    if (below > 0) {
+      span_begin(pr.trsm_spans);
       hipLaunchKernelGGL(k_trsm_block<16>, dim3((below + 15) / 16), dim3(256), 0, s, f.K, f.ldk, Wb,
                          ldw, nrows, c0, nb, f.dinv, f.Linv);
+      span_end(pr.trsm_spans);
+    }
   };
   int buf = 0;
   if (N > 0) {
@@ -833,8 +848,10 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
     const int c1 = c0 + OB, nb1 = std::min(OB, N - c1);
     const double *Wb = f.W + (size_t)buf * f.wstride;
     const int nt = (nb1 + 31) / 32;
+    span_begin(pr.udiag_spans);
     hipLaunchKernelGGL(k_update_diag<32>, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, f.K, f.ldk, Wb,
                        ldw, c0, OB, c1, nb1);
+    span_end(pr.udiag_spans);
     // D(k + 1) and everything of U(k) below the next diagonal block, in one launch; while
     // profiling (per-kernel events) and on request (PGF_FUSED=0) as two launches
     const int row0 = c1 + nb1;

@@ -15,9 +15,14 @@ struct PgfProfile {
   std::vector<hipEvent_t> pool;  // recycled event pairs
   std::vector<std::pair<hipEvent_t, hipEvent_t>> update_spans;
   std::vector<double> update_flops;
+  std::vector<double> update_bytes;  // algorithmic bytes: C tile read + write, both panels once
   std::vector<std::pair<hipEvent_t, hipEvent_t>> factor_spans;
-  double acc_update_ms = 0, acc_update_flops = 0, acc_factor_ms = 0;
-  int64_t acc_update_launches = 0;
+  // look-ahead schedule, instrumented (unfused) pass: the diagonal chain, the TRSM below it
+  // and the diagonal-block update, one span per launch
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> chain_spans, trsm_spans, udiag_spans;
+  double acc_update_ms = 0, acc_update_flops = 0, acc_update_bytes = 0, acc_factor_ms = 0;
+  double acc_chain_ms = 0, acc_trsm_ms = 0, acc_udiag_ms = 0;
+  int64_t acc_update_launches = 0, acc_chain_launches = 0;
 };
 
 // Dense symmetric factor  K = L D L^T  (unit lower L, diagonal D), lower triangle,

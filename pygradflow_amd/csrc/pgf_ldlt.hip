@@ -1295,6 +1295,9 @@ void launch_update(DenseLdlt &f, hipStream_t s, const double *Wp, int64_t ldw, i
       if (top > lo) cnt += top - lo;
     }
     p->update_flops.push_back(2.0 * cnt * KB);
+    // algorithmic HBM bytes: every C entry read and written once, the W rows and the L rows of
+    // the region once each
+    p->update_bytes.push_back(16.0 * cnt + 8.0 * KB * ((double)(nrows - row0) + (double)(colEnd - col0)));
   }
 }
 

@@ -317,11 +317,14 @@ class DeviceNewton:
         _lib.check(self._lib.pgf_profile_enable(self._hd.h, int(on)), self._hd.h)
 
     def profile_read(self):
-        ms, cnt, fl, fms = C.c_double(0), C.c_int64(0), C.c_double(0), C.c_double(0)
-        _lib.check(self._lib.pgf_profile_read(self._hd.h, C.byref(ms), C.byref(cnt), C.byref(fl),
-                                              C.byref(fms)), self._hd.h)
-        return dict(update_ms=ms.value, update_launches=cnt.value, update_flops=fl.value,
-                    factor_ms=fms.value)
+        out = np.zeros(9)
+        _lib.check(self._lib.pgf_profile_read_ex(self._hd.h, _lib.dptr(out), out.size), self._hd.h)
+        keys = ("update_ms", "update_launches", "update_flops", "update_bytes", "factor_ms",
+                "chain_ms", "chain_launches", "trsm_ms", "udiag_ms")
+        rec = dict(zip(keys, (float(v) for v in out)))
+        rec["update_launches"] = int(rec["update_launches"])
+        rec["chain_launches"] = int(rec["chain_launches"])
+        return rec
 
     def close(self):
         if getattr(self, "_hd", None) is not None:
