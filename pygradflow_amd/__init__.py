@@ -8,7 +8,7 @@ reference's default step controller on top of either.  All arithmetic is in ``li
 there is no CPU fallback.
 """
 
-from .errors import LinearSolverError, StepSolverError  # noqa: F401
+from .errors import EvalError, LinearSolverError, StepSolverError  # noqa: F401
 from .params import (  # noqa: F401
     ActiveSetType,
     LinearSolverType,
@@ -40,6 +40,11 @@ def __getattr__(name):
         from . import step_control
 
         return getattr(step_control, name)
+    if name in ("StandardStepSolver", "ExtendedStepSolver", "AsymmetricStepSolver", "step_solver",
+                "UnscaledStepFunc"):
+        from . import unsym_step_solvers
+
+        return getattr(unsym_step_solvers, name)
     if name == "BatchedDeviceNewton":
         from .batched import BatchedDeviceNewton
 

@@ -19,6 +19,7 @@ SOURCES = [
     ("pgf_sparse.hip", ["-ffp-contract=off"]),
     ("pgf_ldlt.hip", ["-DPGF_RECIP_ONE_STEP"] if os.environ.get("PGF_BUILD_RECIP1") else []),
     ("pgf_factor2.hip", []),
+    ("pgf_lu.hip", []),
     ("pgf_api.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]

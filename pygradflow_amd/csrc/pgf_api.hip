@@ -55,8 +55,10 @@ struct pgf_solver {
 
 struct pgf_linsolver {
   int N = 0, device = 0;
+  bool symmetric = true;  // LDL^T (fac) or LU with partial pivoting (lu)
   hipStream_t stream = nullptr;
   DenseLdlt fac;
+  DenseLu lu;
   double *rhs = nullptr, *sol = nullptr;
 };
 
@@ -1533,19 +1535,32 @@ int pgf_profile_read_ex(pgf_handle h, double *out, int count) {
 int pgf_ls_create_dense(int N, const double *A, int64_t lda, int symmetric, int device,
                         pgf_ls_handle *out) {
   if (!out || N < 0 || N > 60000 || (N && (!A || lda < N))) return PGF_INVALID;
-  if (!symmetric) return PGF_INVALID;  // unsymmetric LU: not on the Symmetric path
   hipError_t e = hipSetDevice(device);
   if (e != hipSuccess) return PGF_HIP_ERROR + (int)e;
   pgf_ls_handle ls = new (std::nothrow) pgf_linsolver();
   if (!ls) return PGF_INVALID;
   ls->N = N;
   ls->device = device;
+  ls->symmetric = symmetric != 0;
   int rc = PGF_OK;
   do {
     if ((e = hipStreamCreateWithFlags(&ls->stream, hipStreamNonBlocking)) != hipSuccess) break;
-    if ((e = ldlt_alloc(ls->fac, N, ls->stream)) != hipSuccess) break;
     if ((e = dalloc(&ls->rhs, (size_t)N + 1)) != hipSuccess) break;
     if ((e = dalloc(&ls->sol, (size_t)N + 1)) != hipSuccess) break;
+    if (!ls->symmetric) {  // LU with partial pivoting of the full matrix
+      if ((e = lu_alloc(ls->lu, N, ls->stream)) != hipSuccess) break;
+      if (N) {
+        e = hipMemcpy2DAsync(ls->lu.A, (size_t)ls->lu.ld * sizeof(double), A,
+                             (size_t)lda * sizeof(double), (size_t)N * sizeof(double), N,
+                             hipMemcpyHostToDevice, ls->stream);
+        if (e != hipSuccess) break;
+      }
+      const int st = lu_factor(ls->lu, &e);
+      if (st < 0) break;
+      if (st == 1) rc = PGF_SINGULAR;
+      break;
+    }
+    if ((e = ldlt_alloc(ls->fac, N, ls->stream)) != hipSuccess) break;
     if (N) {
       e = hipMemcpy2DAsync(ls->fac.K, (size_t)ls->fac.ldk * sizeof(double), A,
                            (size_t)lda * sizeof(double), (size_t)N * sizeof(double), N,
@@ -1567,12 +1582,18 @@ int pgf_ls_create_dense(int N, const double *A, int64_t lda, int symmetric, int 
 }
 
 int pgf_ls_solve(pgf_ls_handle ls, const double *rhs, int trans, double *sol) {
-  (void)trans;
   if (!ls || (ls->N && (!rhs || !sol))) return PGF_INVALID;
   if (ls->N == 0) return PGF_OK;
   (void)hipSetDevice(ls->device);
   hipError_t e = hipMemcpyAsync(ls->rhs, rhs, ls->N * sizeof(double), hipMemcpyHostToDevice,
                                 ls->stream);
+  if (!ls->symmetric) {
+    if (e == hipSuccess) e = lu_solve_async(ls->lu, ls->rhs, ls->sol, trans);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(sol, ls->sol, ls->N * sizeof(double), hipMemcpyDeviceToHost, ls->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ls->stream);
+    return e == hipSuccess ? PGF_OK : PGF_HIP_ERROR + (int)e;
+  }
   if (e == hipSuccess) e = ldlt_solve_async(ls->fac, ls->rhs, ls->sol);
   if (e == hipSuccess)
     e = hipMemcpyAsync(sol, ls->sol, ls->N * sizeof(double), hipMemcpyDeviceToHost, ls->stream);
@@ -1591,8 +1612,10 @@ int pgf_ls_get_factor(pgf_ls_handle ls, double *LD_out, int64_t ld) {
   if (!ls || (ls->N && (!LD_out || ld < ls->N))) return PGF_INVALID;
   if (ls->N == 0) return PGF_OK;
   (void)hipSetDevice(ls->device);
-  hipError_t e = hipMemcpy2DAsync(LD_out, (size_t)ld * sizeof(double), ls->fac.K,
-                                  (size_t)ls->fac.ldk * sizeof(double),
+  const double *src = ls->symmetric ? ls->fac.K : ls->lu.A;
+  const int64_t lds = ls->symmetric ? ls->fac.ldk : ls->lu.ld;
+  hipError_t e = hipMemcpy2DAsync(LD_out, (size_t)ld * sizeof(double), src,
+                                  (size_t)lds * sizeof(double),
                                   (size_t)ls->N * sizeof(double), ls->N, hipMemcpyDeviceToHost,
                                   ls->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ls->stream);
@@ -1601,6 +1624,7 @@ int pgf_ls_get_factor(pgf_ls_handle ls, double *LD_out, int64_t ld) {
 
 int pgf_ls_num_neg(pgf_ls_handle ls, int *out) {
   if (!ls || !out) return PGF_INVALID;
+  if (!ls->symmetric) return PGF_NOT_READY;  // an LU has no inertia (LUSolver returns None)
   *out = ls->fac.n_neg;
   return PGF_OK;
 }
@@ -1610,6 +1634,7 @@ int pgf_ls_destroy(pgf_ls_handle ls) {
   (void)hipSetDevice(ls->device);
   if (ls->stream) (void)hipStreamSynchronize(ls->stream);
   ldlt_free(ls->fac);
+  lu_free(ls->lu);
   if (ls->rhs) (void)hipFree(ls->rhs);
   if (ls->sol) (void)hipFree(ls->sol);
   if (ls->stream) (void)hipStreamDestroy(ls->stream);

@@ -76,6 +76,23 @@ hipEvent_t prof_event(PgfProfile *p);
 void launch_update(DenseLdlt &f, hipStream_t s, const double *Wp, int64_t ldw, int N, int nrows,
                    int row0, int col0, int colEnd, int kc0, int KB, PgfProfile *p, int any_order);
 
+// ---- dense LU with partial pivoting (pgf_lu.hip): P A = L U, row-major, in place ----------
+struct DenseLu {
+  int N = 0;
+  int64_t ld = 0;
+  double *A = nullptr;     // N x ld: unit-lower L below the diagonal, U on and above it
+  int *piv = nullptr;      // row interchanged with row i at step i (LAPACK convention)
+  int *perm = nullptr;     // the interchanges as one permutation: (P b)[i] = b[perm[i]]
+  double *work = nullptr;  // N
+  int *flags = nullptr;    // [0] zero / non-finite pivot
+  hipStream_t stream = nullptr;
+  bool factored = false;
+};
+hipError_t lu_alloc(DenseLu &f, int N, hipStream_t stream);
+void lu_free(DenseLu &f);
+int lu_factor(DenseLu &f, hipError_t *err);  // 0 ok / 1 singular / -1 HIP error
+hipError_t lu_solve_async(DenseLu &f, const double *rhs, double *sol, int trans);
+
 // ---- batched mode ----------------------------------------------------------
 // One entry per instance of a batch (all instances share n, m): the device addresses of an
 // ordinary solver handle.  Batched kernels pick their instance with blockIdx.z and read the

@@ -1,0 +1,332 @@
+// Dense LU factorisation with partial (row) pivoting,  P A = L U,  and the solves with A and
+// A^T: the unsymmetric counterpart of pgf_ldlt.hip / pgf_factor2.hip.
+//
+// The reference's default linear solver is LU for EVERY matrix (scipy.sparse.linalg.splu at
+// pygradflow/linear_solver/lu_solver.py:9-21; its `symmetric` flag is ignored there), and three
+// of its four step-solver formulations hand it an unsymmetric (n + m)^2 Newton matrix
+// (step/solver/standard_step_solver.py:40-92, extended_step_solver.py:39-112,
+// asymmetric_step_solver.py:38-173).  This file is the linear solver behind those
+// formulations (HipLinearSolver(symmetric=False)); it is not on the headline path (the
+// symmetric reduced KKT system goes through the LDL^T kernels) and is written for
+// robustness first: classical right-looking blocked LU, panel width 32,
+//   k_lu_panel    ONE workgroup: per column pivot search (max |a|, smallest row on ties),
+//                 swap of the two full rows, scaling, rank-1 update inside the panel
+//   k_lu_trsm     U12 = L11^-1 A12, one lane per column
+//   k_lu_update   A22 -= L21 U12, 64 x 64 tiles, register-blocked fp64 FMAs (on gfx950 the
+//                 vector fp64 FMA rate equals the MFMA rate; at K-depth 32 the update is
+//                 bound by its C traffic anyway)
+// and blocked triangular solves (64-row blocks: k_tri_diag + k_tri_gemv), with a TRANS
+// switch for A^T x = b (LinearSolver.solve(rhs, trans=True), reference
+// linear_solver/linear_solver.py:23-25, used by step/cond_estimate.py:82).
+// A zero or non-finite pivot sets flags[0] -> PGF_SINGULAR -> LinearSolverError, like the
+// RuntimeError of splu (lu_solver.py:13-17).
+#include "pgf_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#define LU_PB 32
+
+__global__ __launch_bounds__(1024) void k_lu_panel(double *A, int64_t ld, int N, int c0, int pb,
+                                                   int *__restrict__ piv, int *__restrict__ flags) {
+  __shared__ double sval[1024];
+  __shared__ int sidx[1024];
+  __shared__ double prow[LU_PB];
+  const int tid = threadIdx.x;
+  for (int j = 0; j < pb; ++j) {
+    const int col = c0 + j;
+    // ---- pivot search over rows col .. N-1 of column col
+    double best = -1.0;
+    int bi = N;
+    for (int r = col + tid; r < N; r += 1024) {
+      const double v = fabs(A[(int64_t)r * ld + col]);
+      if (v > best || (v != v && best == best)) {  // a NaN wins: it must be reported
+        best = v;
+        bi = r;
+      }
+    }
+    sval[tid] = best;
+    sidx[tid] = bi;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+      if (tid < o) {
+        const double v = sval[tid + o], w = sval[tid];
+        const int vi = sidx[tid + o], wi = sidx[tid];
+        const bool take = (v != v && w == w) || (w == w && (v > w || (v == w && vi < wi)));
+        if (take) {
+          sval[tid] = v;
+          sidx[tid] = vi;
+        }
+      }
+      __syncthreads();
+    }
+    const int p = min(sidx[0], N - 1);
+    const double pv = sval[0];
+    if (tid == 0) {
+      piv[col] = p;
+      if (!(pv > 0.0) || !(pv <= 1.79e308)) atomicOr(&flags[0], 1);
+    }
+    // ---- swap the two full rows (L part to the left included, as LAPACK's dgetrf does)
+    if (p != col) {
+      for (int c = tid; c < N; c += 1024) {
+        const double a = A[(int64_t)col * ld + c], b = A[(int64_t)p * ld + c];
+        A[(int64_t)col * ld + c] = b;
+        A[(int64_t)p * ld + c] = a;
+      }
+    }
+    __syncthreads();
+    if (tid < pb) prow[tid] = A[(int64_t)col * ld + c0 + tid];
+    __syncthreads();
+    const double d = prow[j];
+    // ---- multipliers and the rank-1 update of the panel's remaining columns
+    for (int r = col + 1 + tid; r < N; r += 1024) {
+      double *row = A + (int64_t)r * ld + c0;
+      const double l = row[j] / d;
+      row[j] = l;
+      for (int k = j + 1; k < pb; ++k) row[k] = fma(-l, prow[k], row[k]);
+    }
+    __syncthreads();
+  }
+}
+
+// U12 = L11^-1 A12: lane <-> column of A12, the panel's unit-lower L11 broadcast from LDS
+__global__ __launch_bounds__(256) void k_lu_trsm(double *A, int64_t ld, int N, int c0, int pb) {
+  __shared__ double L11[LU_PB][LU_PB + 1];
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < pb * pb; idx += 256) {
+    const int i = idx / pb, k = idx % pb;
+    L11[i][k] = A[(int64_t)(c0 + i) * ld + c0 + k];
+  }
+  __syncthreads();
+  const int j = c0 + pb + blockIdx.x * 256 + tid;
+  if (j >= N) return;
+  double x[LU_PB];
+#pragma unroll
+  for (int k = 0; k < LU_PB; ++k) x[k] = (k < pb) ? A[(int64_t)(c0 + k) * ld + j] : 0.0;
+#pragma unroll
+  for (int k = 0; k < LU_PB; ++k) {
+#pragma unroll
+    for (int i = k + 1; i < LU_PB; ++i)
+      if (i < pb) x[i] = fma(-L11[i][k], x[k], x[i]);
+  }
+#pragma unroll
+  for (int k = 0; k < LU_PB; ++k)
+    if (k < pb) A[(int64_t)(c0 + k) * ld + j] = x[k];
+}
+
+// A22 -= L21 U12 over rows / columns [c1, N), K-depth pb <= 32 (L21 = columns [c0, c0 + pb)
+// of the rows, U12 = rows [c0, c0 + pb) of the columns).  64 x 64 tile per workgroup of 256
+// threads, 4 x 4 entries per thread.
+__global__ __launch_bounds__(256) void k_lu_update(double *A, int64_t ld, int N, int c0, int pb,
+                                                   int c1) {
+  __shared__ double As[64][LU_PB + 1];
+  __shared__ double Bs[LU_PB][64 + 1];
+  const int tid = threadIdx.x;
+  const int i0 = c1 + blockIdx.y * 64, j0 = c1 + blockIdx.x * 64;
+  for (int idx = tid; idx < 64 * LU_PB; idx += 256) {
+    const int r = idx / LU_PB, k = idx % LU_PB;
+    As[r][k] = (i0 + r < N && k < pb) ? A[(int64_t)(i0 + r) * ld + c0 + k] : 0.0;
+  }
+  for (int idx = tid; idx < LU_PB * 64; idx += 256) {
+    const int k = idx / 64, c = idx % 64;
+    Bs[k][c] = (j0 + c < N && k < pb) ? A[(int64_t)(c0 + k) * ld + j0 + c] : 0.0;
+  }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;  // rows ty + 16 a, columns tx + 16 b
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+#pragma unroll 8
+  for (int k = 0; k < LU_PB; ++k) {
+    double av[4], bv[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) av[a] = As[ty + 16 * a][k];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) bv[b] = Bs[k][tx + 16 * b];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int i = i0 + ty + 16 * a;
+    if (i >= N) continue;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int j = j0 + tx + 16 * b;
+      if (j < N) A[(int64_t)i * ld + j] -= acc[a][b];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- triangular solves
+// T(i, k): entry of the triangular factor the solve works with (TRANS reads the stored
+// matrix transposed: U^T is lower, L^T is upper).
+template <bool TRANS>
+__device__ __forceinline__ double tri_at(const double *A, int64_t ld, int i, int k) {
+  return TRANS ? A[(int64_t)k * ld + i] : A[(int64_t)i * ld + k];
+}
+
+// solve the 64-row diagonal block b0: x[b0 .. b0+nb) in place.  One workgroup of 64 lanes;
+// LOWER: forward inside the block, else backward.
+template <bool LOWER, bool UNIT, bool TRANS>
+__global__ __launch_bounds__(64) void k_tri_diag(const double *__restrict__ A, int64_t ld, int N,
+                                                 int b0, double *__restrict__ x) {
+  __shared__ double T[64][65];
+  __shared__ double xs[64];
+  const int tid = threadIdx.x;
+  const int nb = min(64, N - b0);
+  for (int idx = tid; idx < 64 * 64; idx += 64) {
+    const int i = idx >> 6, k = idx & 63;
+    T[i][k] = (i < nb && k < nb) ? tri_at<TRANS>(A, ld, b0 + i, b0 + k) : (i == k ? 1.0 : 0.0);
+  }
+  xs[tid] = (tid < nb) ? x[b0 + tid] : 0.0;
+  __syncthreads();
+  double mine = xs[tid];
+  for (int s = 0; s < nb; ++s) {
+    const int k = LOWER ? s : nb - 1 - s;
+    if (tid == k) {
+      if (!UNIT) mine /= T[k][k];
+      xs[k] = mine;
+    }
+    __syncthreads();
+    const bool later = LOWER ? (tid > k) : (tid < k);
+    if (later && tid < nb) mine = fma(-T[tid][k], xs[k], mine);
+  }
+  if (tid < nb) x[b0 + tid] = mine;
+}
+
+// after block b0 is solved: x[r] -= sum_k T(r, b0 + k) x[b0 + k] for the rows still open
+// (LOWER: r >= b0 + nb, else r < b0); one lane per row
+template <bool LOWER, bool TRANS>
+__global__ __launch_bounds__(256) void k_tri_gemv(const double *__restrict__ A, int64_t ld, int N,
+                                                  int b0, double *__restrict__ x) {
+  __shared__ double xs[64];
+  const int tid = threadIdx.x;
+  const int nb = min(64, N - b0);
+  if (tid < 64) xs[tid] = (tid < nb) ? x[b0 + tid] : 0.0;
+  __syncthreads();
+  const int r = (LOWER ? b0 + nb : 0) + blockIdx.x * 256 + tid;
+  const int rend = LOWER ? N : b0;
+  if (r >= rend) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int k = 0; k + 1 < nb; k += 2) {
+    s0 = fma(tri_at<TRANS>(A, ld, r, b0 + k), xs[k], s0);
+    s1 = fma(tri_at<TRANS>(A, ld, r, b0 + k + 1), xs[k + 1], s1);
+  }
+  if (nb & 1) s0 = fma(tri_at<TRANS>(A, ld, r, b0 + nb - 1), xs[nb - 1], s0);
+  x[r] -= s0 + s1;
+}
+
+// out[i] = in[perm[i]] (gather) or out[perm[i]] = in[i] (scatter)
+__global__ void k_permute(const double *__restrict__ in, const int *__restrict__ perm,
+                          double *__restrict__ out, int N, int scatter) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  if (scatter) out[perm[i]] = in[i];
+  else out[i] = in[perm[i]];
+}
+
+// ---------------------------------------------------------------- host side
+hipError_t lu_alloc(DenseLu &f, int N, hipStream_t stream) {
+  f.N = N;
+  f.ld = ((int64_t)N + 15) / 16 * 16;
+  if (f.ld % 512 == 0) f.ld += 16;
+  f.stream = stream;
+  hipError_t e;
+  const size_t rows = (size_t)std::max(N, 1);
+  if ((e = hipMalloc((void **)&f.A, rows * f.ld * sizeof(double))) != hipSuccess) return e;
+  if ((e = hipMalloc((void **)&f.piv, rows * sizeof(int))) != hipSuccess) return e;
+  if ((e = hipMalloc((void **)&f.perm, rows * sizeof(int))) != hipSuccess) return e;
+  if ((e = hipMalloc((void **)&f.work, rows * sizeof(double))) != hipSuccess) return e;
+  if ((e = hipMalloc((void **)&f.flags, 4 * sizeof(int))) != hipSuccess) return e;
+  return hipSuccess;
+}
+
+void lu_free(DenseLu &f) {
+  if (f.A) (void)hipFree(f.A);
+  if (f.piv) (void)hipFree(f.piv);
+  if (f.perm) (void)hipFree(f.perm);
+  if (f.work) (void)hipFree(f.work);
+  if (f.flags) (void)hipFree(f.flags);
+  f = DenseLu();
+}
+
+// factorise f.A in place; returns 0 ok / 1 singular / -1 HIP error (*err)
+int lu_factor(DenseLu &f, hipError_t *err) {
+  const int N = f.N;
+  hipStream_t s = f.stream;
+  hipError_t e = hipMemsetAsync(f.flags, 0, 4 * sizeof(int), s);
+  for (int c0 = 0; c0 < N && e == hipSuccess; c0 += LU_PB) {
+    const int pb = std::min(LU_PB, N - c0);
+    hipLaunchKernelGGL(k_lu_panel, dim3(1), dim3(1024), 0, s, f.A, f.ld, N, c0, pb, f.piv, f.flags);
+    const int c1 = c0 + pb;
+    if (c1 < N) {
+      hipLaunchKernelGGL(k_lu_trsm, dim3((N - c1 + 255) / 256), dim3(256), 0, s, f.A, f.ld, N, c0, pb);
+      const int t = (N - c1 + 63) / 64;
+      hipLaunchKernelGGL(k_lu_update, dim3(t, t), dim3(256), 0, s, f.A, f.ld, N, c0, pb, c1);
+    }
+    e = hipGetLastError();
+  }
+  std::vector<int> piv((size_t)std::max(N, 1)), perm((size_t)std::max(N, 1));
+  int h_flags[4] = {0, 0, 0, 0};
+  if (e == hipSuccess) e = hipMemcpyAsync(h_flags, f.flags, sizeof(h_flags), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess && N)
+    e = hipMemcpyAsync(piv.data(), f.piv, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (err) *err = e;
+  if (e != hipSuccess) return -1;
+  // the sequence of row interchanges as one permutation: row i of P A is row perm[i] of A
+  for (int i = 0; i < N; ++i) perm[i] = i;
+  for (int i = 0; i < N; ++i) std::swap(perm[i], perm[std::min(std::max(piv[i], 0), N - 1)]);
+  if (N) {
+    e = hipMemcpyAsync(f.perm, perm.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (err) *err = e;
+    if (e != hipSuccess) return -1;
+  }
+  f.factored = (h_flags[0] == 0);
+  return h_flags[0] ? 1 : 0;
+}
+
+template <bool LOWER, bool UNIT, bool TRANS>
+static void tri_solve(DenseLu &f, double *x) {
+  const int N = f.N;
+  hipStream_t s = f.stream;
+  const int nblk = (N + 63) / 64;
+  for (int bi = 0; bi < nblk; ++bi) {
+    const int b = LOWER ? bi : nblk - 1 - bi;
+    const int b0 = b * 64;
+    hipLaunchKernelGGL((k_tri_diag<LOWER, UNIT, TRANS>), dim3(1), dim3(64), 0, s, f.A, f.ld, N, b0, x);
+    const int open = LOWER ? N - std::min(N, b0 + 64) : b0;
+    if (open > 0)
+      hipLaunchKernelGGL((k_tri_gemv<LOWER, TRANS>), dim3((open + 255) / 256), dim3(256), 0, s, f.A,
+                         f.ld, N, b0, x);
+  }
+}
+
+// sol <- A^-1 rhs (trans == 0) or A^-T rhs (device vectors of length N; rhs is preserved)
+hipError_t lu_solve_async(DenseLu &f, const double *rhs, double *sol, int trans) {
+  const int N = f.N;
+  if (N == 0) return hipSuccess;
+  hipStream_t s = f.stream;
+  const dim3 g((N + 255) / 256), b(256);
+  if (!trans) {
+    // P A = L U:  A x = b  <=>  L U x = P b
+    hipLaunchKernelGGL(k_permute, g, b, 0, s, rhs, f.perm, sol, N, 0);
+    tri_solve<true, true, false>(f, sol);
+    tri_solve<false, false, false>(f, sol);
+  } else {
+    // A^T = U^T L^T P:  U^T z = b (lower),  L^T w = z (upper, unit),  x = P^T w
+    hipError_t e = hipMemcpyAsync(f.work, rhs, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return e;
+    tri_solve<true, false, true>(f, f.work);
+    tri_solve<false, true, true>(f, f.work);
+    hipLaunchKernelGGL(k_permute, g, b, 0, s, f.work, f.perm, sol, N, 1);
+  }
+  return hipGetLastError();
+}

@@ -23,22 +23,19 @@ class HipLinearSolver:
         dense = _lib.as_f64(dense)
         if dense.ndim != 2 or dense.shape[0] != dense.shape[1]:
             raise ValueError("square matrix expected")
-        if not symmetric:
-            # the LU back-end of the reference ignores the flag (lu_solver.py:9-17); this
-            # factor needs symmetry, so verify it instead of trusting the caller
-            if not np.array_equal(dense, dense.T):
-                raise NotImplementedError(
-                    "HipLinearSolver factors symmetric matrices (LDL^T); the unsymmetric "
-                    "step-solver formulations are not on the Symmetric hot path"
-                )
+        # symmetric=True: LDL^T of the lower triangle (the Symmetric step solver's reduced KKT
+        # matrix); symmetric=False: LU with partial pivoting of the full matrix, which is what
+        # the reference's LUSolver does for every matrix (lu_solver.py:9-17)
         self.shape = dense.shape
         self._lib = _lib.load()
         self._h = C.c_void_p()
         n = dense.shape[0]
-        rc = self._lib.pgf_ls_create_dense(n, _lib.dptr(dense), max(n, 1), 1, device, C.byref(self._h))
+        rc = self._lib.pgf_ls_create_dense(n, _lib.dptr(dense), max(n, 1), int(bool(symmetric)),
+                                           device, C.byref(self._h))
         if rc != _lib.PGF_OK:
             self._h = C.c_void_p()
-        _lib.check(rc, None, "LDL^T factorisation failed" if rc == _lib.PGF_SINGULAR else "pgf_ls_create_dense")
+        what = "LDL^T" if symmetric else "LU"
+        _lib.check(rc, None, f"{what} factorisation failed" if rc == _lib.PGF_SINGULAR else "pgf_ls_create_dense")
 
     def solve(self, rhs, trans: bool = False, initial_sol=None):
         rhs = _lib.as_f64(rhs)
@@ -50,17 +47,20 @@ class HipLinearSolver:
         return sol
 
     def num_neg_eigvals(self):
+        if not self.symmetric:
+            return None  # an LU carries no inertia (reference LUSolver: base-class None)
         out = C.c_int(0)
         _lib.check(self._lib.pgf_ls_num_neg(self._h, C.byref(out)), None, "pgf_ls_num_neg")
         return out.value
 
     def factor_matrix(self):
-        """Unit-lower L (below the diagonal) and D (on it), as factored on the device."""
+        """LDL^T: unit-lower L (below the diagonal) and D (on it); LU: L below, U on and above
+        the diagonal (rows in pivoted order) -- as factored on the device."""
         n = self.shape[0]
         out = np.zeros((n, n))
         if n:
             _lib.check(self._lib.pgf_ls_get_factor(self._h, _lib.dptr(out), n), None, "pgf_ls_get_factor")
-        return np.tril(out)
+        return np.tril(out) if self.symmetric else out
 
     def rcond(self):
         return None

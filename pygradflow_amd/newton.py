@@ -132,16 +132,11 @@ class GlobalizedNewtonMethod(NewtonMethod):
 
 def make_step_solver(problem, params, iterate, dt, rho):
     """Reference factory ``step_solver`` (step/solver/__init__.py:12-31): honours the
-    ``params.step_solver`` hook, defaults to the HIP solver (Symmetric formulation)."""
-    hook = getattr(params, "step_solver", None)
-    if hook is not None:
-        return hook(problem, params, iterate, dt, rho)
-    kind = enum_name(getattr(params, "step_solver_type", "Symmetric"))
-    if kind != "Symmetric":
-        raise NotImplementedError(
-            f"step_solver_type {kind}: only the Symmetric formulation is on the HIP hot path"
-        )
-    return HipStepSolver(problem, params, iterate, dt, rho)
+    ``params.step_solver`` hook, then ``params.step_solver_type``: Symmetric (default) is the
+    HIP hot path, Standard / Extended / Asymmetric go through the GPU LU."""
+    from .unsym_step_solvers import step_solver
+
+    return step_solver(problem, params, iterate, dt, rho)
 
 
 def newton_method(problem, params, iterate, dt, rho, tau=None):

@@ -15,8 +15,13 @@ def case_names():
         os.path.basename(p)[:-4]
         for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
         if not p.endswith("linear_solver_5x5.npz")
-        and not os.path.basename(p).startswith(("extras_", "ctl_", "measures_"))
+        and not os.path.basename(p).startswith(("extras_", "ctl_", "measures_", "formul_",
+                                                "linear_solver_"))
     )
+
+
+def formulation_case_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "formul_*.npz")))
 
 
 def controller_case_names():

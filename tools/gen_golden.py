@@ -218,6 +218,64 @@ def run_controller_case(name, problem, x0, y0, rho, iterations, newton_type, sto
           f"lamb {rec['lamb'][0]:.3g} -> {rec['lamb_next'][-1]:.3g}")
 
 
+def run_formulations(name, problem, x0, y0, dt, rho, steps, store_problem, tau=None):
+    """The reference's three unsymmetric step-solver formulations (step/solver/
+    standard_step_solver.py, extended_step_solver.py, asymmetric_step_solver.py) under every
+    Newton policy: per step the mask, the step and the new point; for the first step also the
+    assembled Newton matrix, its right-hand side and the LU solution."""
+    from pygradflow.params import StepSolverType
+
+    out = dict(n=problem.num_vars, m=problem.num_cons, dt=dt, rho=rho, steps=steps,
+               tau=np.nan if tau is None else tau,
+               x0=np.asarray(x0, float), y0=np.asarray(y0, float),
+               var_lb=problem.var_lb, var_ub=problem.var_ub,
+               policies=np.array(POLICIES), kinds=np.array(["Standard", "Extended", "Asymmetric"]))
+    for k, v in store_problem.items():
+        out["problem/" + k] = v
+    for kind in ("Standard", "Extended", "Asymmetric"):
+        for pol in POLICIES:
+            kw = {}
+            if tau is not None:
+                kw = dict(active_set_type="Explicit", active_set_tau=tau)
+            params = Params(newton_type=NewtonType[pol], step_solver_type=StepSolverType[kind], **kw)
+            orig = Iterate(problem, params, np.asarray(x0, float), np.asarray(y0, float))
+            method = newton_method(problem, params, orig, dt, rho, tau)
+            it = orig
+            for k in range(steps):
+                step = method.step(it)
+                ss = method.step_solver
+                pre = f"{kind}/{pol}/{k}/"
+                out[pre + "mask"] = np.asarray(step.active_set)
+                out[pre + "dx"], out[pre + "dy"] = step.dx, step.dy
+                out[pre + "xn"], out[pre + "yn"] = step.iterate.x, step.iterate.y
+                out[pre + "diff"] = step.diff
+                if k == 0:
+                    out[pre + "deriv"] = _dense(ss.deriv)
+                    out[pre + "F"] = ss.func.value_at(it, rho, np.asarray(step.active_set))
+                it = step.iterate
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: formulations written")
+
+
+def lu_cases():
+    """Unsymmetric systems through the reference's LUSolver (lu_solver.py:9-21), plain and
+    transposed solves; a singular matrix must raise LinearSolverError there."""
+    rng = np.random.default_rng(7)
+    out = {}
+    for nm, n in (("n7", 7), ("n40", 40), ("n150", 150)):
+        A = rng.standard_normal((n, n)) + 0.5 * np.diag(rng.standard_normal(n))
+        # make pivoting matter: a tiny leading entry and a row that must move far
+        A[0, 0] = 1e-14
+        A[[1, n - 1]] = A[[n - 1, 1]]
+        rhs = rng.standard_normal(n)
+        sv = linear_solver(sps.csc_matrix(A), LinearSolverType.LU, symmetric=False)
+        out[nm + "/mat"], out[nm + "/rhs"] = A, rhs
+        out[nm + "/sol"] = sv.solve(rhs)
+        out[nm + "/sol_trans"] = sv.solve(rhs, trans=True)
+    np.savez_compressed(os.path.join(OUT, "linear_solver_lu.npz"), **out)
+    print("linear_solver_lu written")
+
+
 def qp_store(prob):
     return dict(kind="lq", Q=prob.hess_dense(), q=prob.q, A=prob.jac_dense(), b=prob.b)
 
@@ -403,9 +461,21 @@ def main():
     run_extras("extras_dense_qp_boxed_n96_m24", d2b, np.zeros(96), np.zeros(24), 0.1, 1.0, 3,
                qp_store(d2b))
 
+    # ---- the three unsymmetric formulations under every policy
+    Tame2 = _ref_fixture("tame", "Tame")
+    run_formulations("formul_quartic_n12_m4", qn, x0, np.zeros(4), 0.5, 0.7, 3, quartic_store(qn))
+    run_formulations("formul_quartic_n12_m4_tau", qn, x0, np.zeros(4), 0.5, 0.7, 2,
+                     quartic_store(qn), tau=0.3)
+    run_formulations("formul_dense_qp_boxed_n96_m24", d2b, np.zeros(96), np.zeros(24), 1.0, 1.0, 3,
+                     qp_store(d2b))
+    b5s = P.box_qp(64, seed=0)
+    run_formulations("formul_box_qp_n64", b5s, np.zeros(64), [], 1.0, 1.0, 3, qp_store(b5s))
+    del Tame2
+
     controller_cases()
     measures_cases()
     linear_solver_cases()
+    lu_cases()
 
 
 if __name__ == "__main__":
