@@ -269,6 +269,20 @@ int pgf_ls_destroy(pgf_ls_handle ls);
 int pgf_bench_update(int N, int KB, int variant, int reps, int device, double *ms_out,
                      double *flops_out);
 
+/* ---- accuracy guard of the dense path ---------------------------------------------- */
+/* The reference factorises the reduced KKT matrix with a PIVOTED sparse LU (SuperLU through
+ * scipy.sparse.linalg.splu, linear_solver/lu_solver.py:14) and therefore stays accurate when
+ * H[I,I] + lambda I is indefinite (symmetric_step_solver.py:146-153 only checks the inertia on
+ * request).  The unpivoted LDL^T used here is checked instead: after every solve
+ * max |rhs - K s| is compared with tol * max |rhs| (K applied from H, J and the mask); beyond
+ * that, up to two steps of iterative refinement, then a dense LU with partial pivoting of the
+ * same matrix; PGF_SINGULAR only if that fails as well.  mode 0 switches the check off;
+ * tol / fail_tol <= 0 keep the defaults (1e-11, 1e-7). */
+int pgf_set_refinement(pgf_handle h, int mode, double tol, double fail_tol);
+/* counters since pgf_create: refinement steps taken, LU factorisations, and the relative
+ * residual of the last checked solve */
+int pgf_refinement_stats(pgf_handle h, int *refined, int *lu_fallbacks, double *last_rel_residual);
+
 /* ---- test hooks ------------------------------------------------------------------ */
 /* The triangular solves of the dense path run as ONE launch whose workgroups hand the
  * solution over block by block; every such solve checks itself (placement of its workers,

@@ -51,6 +51,17 @@ struct pgf_solver {
   PgfProfile prof;
   bool step_pending = false;
   int last_solve = 0;  // what newton_core_async enqueued: 1 back-solve of row N, 2 full solve
+  // residual check of the reduced system (dense mode): scratch vectors, r = rhs - K s, the
+  // correction, [max |r|, max |rhs|, max |s|] on device and pinned host; the pivoted LU that
+  // takes over when refinement does not converge (allocated on first use)
+  double *rs_v = nullptr, *rs_lv = nullptr, *rs_u = nullptr, *rs_wy = nullptr, *rs_r = nullptr,
+         *rs_d = nullptr, *rs_red = nullptr, *h_rs = nullptr;
+  DenseLu lu;
+  bool lu_active = false;       // the current factor is the LU (until the next factorisation)
+  int refine_mode = 1;          // 0 off, 1 check + refine on demand (default)
+  double refine_tol = 1e-11, refine_fail = 1e-7;
+  int stat_refined = 0, stat_lu = 0;
+  double stat_last_rel = 0.0;
 };
 
 struct pgf_linsolver {
@@ -146,14 +157,19 @@ int pgf_create(int n, int m, int device, unsigned flags, pgf_handle *out) {
   A_(rhs, N + 1) A_(sol, N + 1) A_(dx, n) A_(dy, m);
   A_(q, n) A_(b, m) A_(w, m) A_(tmpn, n) A_(partial, (size_t)PGF_GEMVT_PARTS * (n ? n : 1));
   A_(red, (N + 255) / 256 + 1) A_(scal, 4) A_(meas, 4 * ((N + 255) / 256) + 4);
+  if (!sparse) {
+    A_(rs_v, n) A_(rs_lv, n) A_(rs_u, n) A_(rs_wy, m) A_(rs_r, N + 1) A_(rs_d, N + 1) A_(rs_red, 4);
+  }
   A_(mask, n) A_(mask_new, n) A_(idxI, n) A_(idxA, n) A_(pos, n) A_(counts, 4);
 #undef A_
   if ((e = hipHostMalloc((void **)&h->h_counts, 4 * sizeof(int))) != hipSuccess ||
       (e = hipHostMalloc((void **)&h->h_scal, 4 * sizeof(double))) != hipSuccess ||
-      (e = hipHostMalloc((void **)&h->h_meas, 4 * sizeof(double))) != hipSuccess) {
+      (e = hipHostMalloc((void **)&h->h_meas, 4 * sizeof(double))) != hipSuccess ||
+      (e = hipHostMalloc((void **)&h->h_rs, 4 * sizeof(double))) != hipSuccess) {
     pgf_destroy(h);
     return PGF_HIP_ERROR + (int)e;
   }
+  for (int i = 0; i < 4; ++i) h->h_rs[i] = 0.0;
   h->sparse = sparse;
   if (sparse) {
     // banded mode: no dense N x N storage; only the factor's flag words are shared
@@ -182,9 +198,12 @@ int pgf_destroy(pgf_handle h) {
                   h->x,    h->y,    h->xn,  h->yn,   h->g,    h->c,        h->F,    h->b0full,
                   h->rhs,  h->sol,  h->dx,  h->dy,   h->q,    h->b,        h->w,    h->tmpn,
                   h->partial, h->red, h->scal, h->mask, h->mask_new, h->idxI, h->idxA, h->pos,
-                  h->counts, h->meas};
+                  h->counts, h->meas, h->rs_v, h->rs_lv, h->rs_u, h->rs_wy, h->rs_r, h->rs_d,
+                  h->rs_red};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
+  if (h->h_rs) (void)hipHostFree(h->h_rs);
+  lu_free(h->lu);
   if (h->h_counts) (void)hipHostFree(h->h_counts);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   if (h->h_meas) (void)hipHostFree(h->h_meas);
@@ -223,7 +242,10 @@ static int down(pgf_handle h, void *dst, const void *src, size_t bytes) {
   return PGF_OK;
 }
 
-static void invalidate_factor(pgf_handle h) { h->fac.factored = false; }
+static void invalidate_factor(pgf_handle h) {
+  h->fac.factored = false;
+  h->lu_active = false;
+}
 
 int pgf_set_bounds(pgf_handle h, const double *lb, const double *ub) {
   if (!h) return PGF_INVALID;
@@ -466,6 +488,7 @@ static int factor_async(pgf_handle h, bool with_rhs) {
     h->fac.factored = false;
     return PGF_OK;
   }
+  h->lu_active = false;
   assemble(h, h->fac.K, h->fac.ldk);
   if (with_rhs && h->N > 0)
     launch_copy(h->stream, h->fac.K + (int64_t)h->N * h->fac.ldk, h->rhs, h->N);
@@ -487,6 +510,96 @@ static void enqueue_step_update(pgf_handle h) {
                      h->scal);
 }
 
+// r = rhs - K s of the solve just enqueued, with K applied from H, J and the mask (the factor
+// overwrote the assembled matrix); the three maxima reach the host with the next sync
+static void enqueue_residual(pgf_handle h) {
+  if (h->sparse || !h->refine_mode) return;
+  launch_kkt_residual(h->stream, h->n, h->m, h->nI, h->lamb, h->delta, h->H, h->ldh, h->J, h->ldj,
+                      h->idxI, h->pos, h->mask, h->rhs, h->sol, h->rs_v, h->rs_lv, h->rs_u, h->rs_wy,
+                      h->partial, PGF_GEMVT_PARTS, h->rs_r, h->rs_red);
+  (void)hipMemcpyAsync(h->h_rs, h->rs_red, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+}
+
+static double residual_rel(pgf_handle h) {
+  const double r = h->h_rs[0], b = h->h_rs[1];
+  if (!(r == r) || !(r <= 1.79e308)) return HUGE_VAL;
+  return r / (b > 0.0 ? b : 1.0);
+}
+
+// After a host synchronisation (and chain_recover): the unpivoted LDL^T is backward stable only
+// while the reduced KKT matrix is quasi-definite and not too ill-conditioned -- with an
+// indefinite H[I,I] + lambda I (non-convex problems at large dt) element growth is unbounded,
+// and the reference's pivoted LU (lu_solver.py:14) has no such limit.  The residual of every
+// solve is therefore checked, max |rhs - K s| <= refine_tol max |rhs|; beyond that up to two
+// steps of iterative refinement with the same factor, and if they do not get below
+// refine_fail either, the reduced matrix is assembled once more and factorised by the LU with
+// partial pivoting of pgf_lu.hip (kept for the back-solve steps that follow).  Only when that
+// fails too does the call report PGF_SINGULAR -> LinearSolverError -> the step controller's
+// reject-and-halve path.
+static int refine_if_needed(pgf_handle h, bool swapped, bool with_step = true) {
+  if (h->sparse || !h->refine_mode || h->N == 0) return PGF_OK;
+  double rel = residual_rel(h);
+  h->stat_last_rel = rel;
+  if (rel <= h->refine_tol) return PGF_OK;
+  hipStream_t s = h->stream;
+  auto unswap = [&]() {
+    if (swapped) {
+      std::swap(h->x, h->xn);
+      std::swap(h->y, h->yn);
+    }
+  };
+  auto finish_round = [&]() -> int {
+    enqueue_residual(h);
+    if (with_step) {
+      unswap();
+      enqueue_step_update(h);
+      unswap();
+      HIPCHK(h, hipMemcpyAsync(h->h_scal, h->scal, sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(h, hipStreamSynchronize(s));
+    if (ldlt_chain_check(h->fac)) return fail(h, PGF_HIP_ERROR, k_chain_msg);
+    return PGF_OK;
+  };
+  int rc;
+  for (int it = 0; it < 2 && rel > h->refine_tol && rel < 1.0 && !h->lu_active; ++it) {
+    HIPCHK(h, ldlt_solve_async(h->fac, h->rs_r, h->rs_d));
+    launch_axpy1(s, h->N, h->rs_d, h->sol);
+    if ((rc = finish_round())) return rc;
+    ++h->stat_refined;
+    const double now = residual_rel(h);
+    if (!(now < rel)) {  // not contracting: leave it to the pivoted factorisation
+      rel = now;
+      break;
+    }
+    rel = now;
+  }
+  h->stat_last_rel = rel;
+  if (rel <= h->refine_fail) return PGF_OK;
+  // pivoted LU of the reduced matrix
+  if (!h->lu_active) {
+    if (!h->lu.A || h->lu.N != h->N) {
+      lu_free(h->lu);
+      HIPCHK(h, lu_alloc(h->lu, h->N, s));
+    }
+    HIPCHK(h, hipMemsetAsync(h->lu.A, 0, (size_t)h->lu.N * h->lu.ld * sizeof(double), s));
+    assemble(h, h->lu.A, h->lu.ld);
+    launch_symmetrize(s, h->lu.A, h->lu.ld, h->N);
+    hipError_t e;
+    const int st = lu_factor(h->lu, &e);
+    if (st < 0) return hip_fail(h, e, "LU fallback");
+    if (st == 1) return fail(h, PGF_SINGULAR, "reduced KKT matrix is singular (LDL^T unstable, LU failed)");
+    h->lu_active = true;
+    ++h->stat_lu;
+  }
+  HIPCHK(h, lu_solve_async(h->lu, h->rhs, h->sol, 0));
+  if ((rc = finish_round())) return rc;
+  rel = residual_rel(h);
+  h->stat_last_rel = rel;
+  if (!(rel <= h->refine_fail))
+    return fail(h, PGF_SINGULAR, "reduced KKT system could not be solved to a small residual");
+  return PGF_OK;
+}
+
 // After a host synchronisation: a chained triangular solve that failed its own checks
 // (placement, timeout) has left garbage in h->sol and whatever was derived from it.  The
 // chain is off from now on (ldlt_chain_check); the solve and the step update are enqueued
@@ -502,6 +615,7 @@ static int chain_recover(pgf_handle h, bool swapped) {
     HIPCHK(h, ldlt_backsolve_async(h->fac, h->fac.K + (int64_t)h->N * h->fac.ldk, h->sol));
   else
     HIPCHK(h, ldlt_solve_async(h->fac, h->rhs, h->sol));
+  enqueue_residual(h);
   enqueue_step_update(h);
   if (swapped) {
     std::swap(h->x, h->xn);
@@ -586,11 +700,16 @@ static int newton_core_async(pgf_handle h, bool *did_factor) {
     if ((rc = factor_async(h, true))) return rc;
     *did_factor = true;
     h->last_solve = 1;
+    h->lu_active = false;
     HIPCHK(h, ldlt_backsolve_async(h->fac, h->fac.K + (int64_t)h->N * h->fac.ldk, h->sol));
   } else {
     h->last_solve = 2;
-    HIPCHK(h, ldlt_solve_async(h->fac, h->rhs, h->sol));
+    if (h->lu_active)
+      HIPCHK(h, lu_solve_async(h->lu, h->rhs, h->sol, 0));
+    else
+      HIPCHK(h, ldlt_solve_async(h->fac, h->rhs, h->sol));
   }
+  enqueue_residual(h);
   enqueue_step_update(h);
   return PGF_OK;
 }
@@ -617,6 +736,7 @@ int pgf_newton_solve(pgf_handle h, const double *x, const double *y, const doubl
     HIPCHK(h, hipStreamSynchronize(h->stream));
   }
   if ((rc = chain_recover(h, false))) return rc;
+  if ((rc = refine_if_needed(h, false))) return rc;
   if (inertia_check && h->fac.n_neg != h->m) return fail(h, PGF_INERTIA, "Invalid matrix inertia");
   if (dx && (rc = down(h, dx, h->dx, h->n * sizeof(double)))) return rc;
   if (dy && (rc = down(h, dy, h->dy, h->m * sizeof(double)))) return rc;
@@ -666,15 +786,24 @@ int pgf_linear_solve(pgf_handle h, const double *rhs, int trans, double *sol) {
     if ((rc = factor_finish(h))) return rc;
   }
   if ((rc = up(h, h->rhs, rhs, h->N * sizeof(double)))) return rc;
+  if (h->lu_active) {  // the pivoted factor took over for this matrix (refine_if_needed)
+    HIPCHK(h, lu_solve_async(h->lu, h->rhs, h->sol, 0));
+    if ((rc = down(h, sol, h->sol, h->N * sizeof(double)))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PGF_OK;
+  }
   HIPCHK(h, ldlt_solve_async(h->fac, h->rhs, h->sol));
-  if ((rc = down(h, sol, h->sol, h->N * sizeof(double)))) return rc;
+  enqueue_residual(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (ldlt_chain_check(h->fac)) {  // the chain is off now: once more with the per-block kernels
     HIPCHK(h, ldlt_solve_async(h->fac, h->rhs, h->sol));
-    if ((rc = down(h, sol, h->sol, h->N * sizeof(double)))) return rc;
+    enqueue_residual(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (ldlt_chain_check(h->fac)) return fail(h, PGF_HIP_ERROR, k_chain_msg);
   }
+  if ((rc = refine_if_needed(h, false, false))) return rc;
+  if ((rc = down(h, sol, h->sol, h->N * sizeof(double)))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   return PGF_OK;
 }
 
@@ -966,8 +1095,25 @@ int pgf_qp_sync(pgf_handle h, int *n_neg, double *diff) {
   if (st == 1) return fail(h, PGF_SINGULAR, "zero or non-finite pivot in LDL^T of the KKT matrix");
   int rc;
   if ((rc = chain_recover(h, true))) return rc;
+  if ((rc = refine_if_needed(h, true))) return rc;
   if (n_neg) *n_neg = h->fac.n_neg;
   if (diff) *diff = h->h_scal[0];
+  return PGF_OK;
+}
+
+int pgf_set_refinement(pgf_handle h, int mode, double tol, double fail_tol) {
+  if (!h || mode < 0 || mode > 1) return PGF_INVALID;
+  h->refine_mode = mode;
+  if (tol > 0.0) h->refine_tol = tol;
+  if (fail_tol > 0.0) h->refine_fail = fail_tol;
+  return PGF_OK;
+}
+
+int pgf_refinement_stats(pgf_handle h, int *refined, int *lu_fallbacks, double *last_rel_residual) {
+  if (!h) return PGF_INVALID;
+  if (refined) *refined = h->stat_refined;
+  if (lu_fallbacks) *lu_fallbacks = h->stat_lu;
+  if (last_rel_residual) *last_rel_residual = h->stat_last_rel;
   return PGF_OK;
 }
 

@@ -46,3 +46,12 @@ void launch_measures(hipStream_t s, int n, int m, double active_tol, const doubl
                      const double *ub, double *red, double *out);
 void launch_csr_to_dense(hipStream_t s, int rows, const int *ptr, const int *idx, const double *val,
                          double *dst, int64_t ld);
+// r = rhs - K s of the reduced KKT system, K applied from H, J and the mask (never assembled);
+// red3 <- max |r|, max |rhs|, max |s|.  v, lv, u: n-vectors of scratch, wy: m, r: nI + m.
+void launch_kkt_residual(hipStream_t s, int n, int m, int nI, double lamb, double delta,
+                         const double *H, int64_t ldh, const double *J, int64_t ldj,
+                         const int *idxI, const int *pos, const uint8_t *mask, const double *rhs,
+                         const double *sol, double *v, double *lv, double *u, double *wy,
+                         double *partial, int nparts, double *r, double *red3);
+void launch_axpy1(hipStream_t s, int N, const double *d, double *x);
+void launch_symmetrize(hipStream_t s, double *A, int64_t ld, int N);

@@ -717,6 +717,91 @@ void launch_csr_to_dense(hipStream_t s, int rows, const int *ptr, const int *idx
                        dst, ld);
 }
 
+// ---------------------------------------------------------------- residual of the reduced system
+// v <- the reduced solution's variable part scattered to the full index set (zero on the
+// active set), lv <- lambda v
+__global__ void k_expand_sol(int n, int nI, const int *__restrict__ pos, const uint8_t *__restrict__ mask,
+                             const double *__restrict__ sol, double lamb, double *__restrict__ v,
+                             double *__restrict__ lv) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const double val = mask[j] ? 0.0 : sol[pos[j]];
+  v[j] = val;
+  lv[j] = lamb * val;
+}
+
+// r = rhs - K s from u = H v + lambda v + J' s_y (full length n) and wy = J v - delta s_y;
+// red[0..2] <- max |r|, max |rhs|, max |s| (bit patterns of non-negative doubles order like
+// integers; red zeroed by the caller)
+__global__ __launch_bounds__(256) void k_kkt_residual(int N, int nI, const int *__restrict__ idxI,
+                                                      const double *__restrict__ rhs,
+                                                      const double *__restrict__ sol,
+                                                      const double *__restrict__ u,
+                                                      const double *__restrict__ wy,
+                                                      double *__restrict__ r,
+                                                      unsigned long long *__restrict__ red) {
+  __shared__ double sh[3][256];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double ar = 0.0, ab = 0.0, as = 0.0;
+  if (i < N) {
+    const double ks = i < nI ? u[idxI[i]] : wy[i - nI];
+    const double ri = rhs[i] - ks;
+    r[i] = ri;
+    ar = fabs(ri);
+    ab = fabs(rhs[i]);
+    as = fabs(sol[i]);
+    if (ar != ar) ar = __builtin_inf();  // a NaN must not vanish in the max
+  }
+  sh[0][threadIdx.x] = ar;
+  sh[1][threadIdx.x] = ab;
+  sh[2][threadIdx.x] = as;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+      for (int q = 0; q < 3; ++q)
+        sh[q][threadIdx.x] = fmax(sh[q][threadIdx.x], sh[q][threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) atomicMax(&red[threadIdx.x], (unsigned long long)__double_as_longlong(sh[threadIdx.x][0]));
+}
+
+__global__ void k_axpy1(int N, const double *__restrict__ d, double *__restrict__ s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) s[i] += d[i];
+}
+
+// full symmetric matrix from its lower triangle (LU fallback of the reduced KKT system)
+__global__ void k_symmetrize(double *__restrict__ A, int64_t ld, int N) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (i < N && j < N && j > i) A[(int64_t)i * ld + j] = A[(int64_t)j * ld + i];
+}
+
+void launch_kkt_residual(hipStream_t s, int n, int m, int nI, double lamb, double delta,
+                         const double *H, int64_t ldh, const double *J, int64_t ldj,
+                         const int *idxI, const int *pos, const uint8_t *mask, const double *rhs,
+                         const double *sol, double *v, double *lv, double *u, double *wy,
+                         double *partial, int nparts, double *r, double *red3) {
+  const int N = nI + m;
+  (void)hipMemsetAsync(red3, 0, 3 * sizeof(double), s);
+  if (N == 0) return;
+  if (n) hipLaunchKernelGGL(k_expand_sol, g1(n), dim3(256), 0, s, n, nI, pos, mask, sol, lamb, v, lv);
+  // u = H v + (lambda v + J' s_y)
+  launch_gemvT(s, m, n, J, ldj, sol + nI, lv, partial, nparts, u);
+  launch_gemv_rows(s, n, n, H, ldh, v, u, 1.0, lv);  // lv is free again: it receives H v + u
+  // wy = J v - delta s_y
+  launch_gemv_rows(s, m, n, J, ldj, v, sol + nI, -delta, wy);
+  hipLaunchKernelGGL(k_kkt_residual, g1(N), dim3(256), 0, s, N, nI, idxI, rhs, sol, lv, wy, r,
+                     reinterpret_cast<unsigned long long *>(red3));
+}
+
+void launch_axpy1(hipStream_t s, int N, const double *d, double *x) {
+  if (N) hipLaunchKernelGGL(k_axpy1, g1(N), dim3(256), 0, s, N, d, x);
+}
+
+void launch_symmetrize(hipStream_t s, double *A, int64_t ld, int N) {
+  if (N) hipLaunchKernelGGL(k_symmetrize, dim3((N + 255) / 256, N), dim3(256), 0, s, A, ld, N);
+}
+
 // ================================================================ batched kernels
 // Same bodies as above, one instance per blockIdx.z, sizes read on the device (BInst in
 // pgf_internal.h).  Nothing here needs a host round trip.

@@ -384,6 +384,14 @@ class HipStepSolver:
             _lib.check(self._lib.pgf_get_kkt(self._hd.h, _lib.dptr(K), N), self._hd.h, "pgf_get_kkt")
         return K
 
+    def refinement_stats(self):
+        """(refinement steps, LU fallbacks, relative residual of the last checked solve) of
+        the device handle this solver uses (``pgf_refinement_stats``)."""
+        a, b, r = C.c_int(0), C.c_int(0), C.c_double(0.0)
+        _lib.check(self._lib.pgf_refinement_stats(self._hd.h, C.byref(a), C.byref(b), C.byref(r)),
+                   self._hd.h)
+        return a.value, b.value, r.value
+
     def solver_for_tests(self):
         """``LinearSolver`` view of the device factor without taking a step (parity tests:
         the factorisation is triggered by the first ``solve`` / ``num_neg_eigvals``)."""

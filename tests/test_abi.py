@@ -87,20 +87,19 @@ def test_shard_ranges_cover_every_instance_once():
             assert seen == list(range(B))
 
 
-def test_unsupported_step_solver_formulations_say_so():
-    """Standard / Extended / Asymmetric are alternative routes to the same Newton step; asking
-    the factory for them without a plugin must not silently run something else."""
+def test_float32_params_are_refused_by_every_formulation():
+    """The HIP solvers compute in float64 only (Precision.Single is outside the 1e-10 parity
+    contract): all four formulations say so instead of silently widening."""
     import numpy as np
     import pytest
 
     from pygradflow_amd import problems
     from pygradflow_amd.iterate import Iterate
-    from pygradflow_amd.newton import make_step_solver
     from pygradflow_amd.params import Params
+    from pygradflow_amd.unsym_step_solvers import StandardStepSolver
 
     prob = problems.dense_qp(8, 2, seed=0)
-    for kind in ("Standard", "Extended", "Asymmetric"):
-        par = Params(step_solver_type=kind)
-        it = Iterate(prob, par, np.zeros(8), np.zeros(2))
-        with pytest.raises(NotImplementedError, match=kind):
-            make_step_solver(prob, par, it, 1.0, 1.0)
+    par = Params(precision="Single")
+    it = Iterate(prob, par, np.zeros(8, dtype=np.float32), np.zeros(2, dtype=np.float32))
+    with pytest.raises(ValueError, match="float64"):
+        StandardStepSolver(prob, par, it, 1.0, 1.0)
