@@ -23,7 +23,7 @@ from . import _lib
 from .errors import LinearSolverError, StepSolverError
 from .params import enum_name
 from .sparse import MAX_BANDWIDTH, BandPlan
-from .step_solver import DENSE_LIMIT, POOL, HipStepSolver
+from .step_solver import DENSE_LIMIT, POOL, HipStepSolver, residency_key, same_key
 
 
 # --------------------------------------------------------------------------- policies
@@ -200,11 +200,9 @@ class DeviceNewton:
         lib = self._lib
         lb, ub = _lib.as_f64(problem.var_lb), _lib.as_f64(problem.var_ub)
         _lib.check(lib.pgf_set_bounds(h, _lib.dptr(lb), _lib.dptr(ub)), h, "pgf_set_bounds")
-        key = getattr(problem, "_pgf_token", None)
-        if key is None:
-            key = object()
-            problem._pgf_token = key
-        if self.sparse and (self._hd.derivs_key is not key or not getattr(self._hd, "qp_loaded", False)):
+        key = residency_key(problem)
+        stale = not same_key(key, self._hd.derivs_key)
+        if self.sparse and (stale or not getattr(self._hd, "qp_loaded", False)):
             plan = BandPlan(problem.hess_sparse(), problem.jac_sparse(), self.n, self.m)
             if not plan.supported:
                 raise NotImplementedError(f"banded path: half-bandwidth {plan.bw} > {MAX_BANDWIDTH}")
@@ -217,7 +215,7 @@ class DeviceNewton:
             self._hd.plan = plan
             self._hd.derivs_key = key
             self._hd.qp_loaded = True
-        elif self._hd.derivs_key is not key or not getattr(self._hd, "qp_loaded", False):
+        elif stale or not getattr(self._hd, "qp_loaded", False):
             Q = np.ascontiguousarray(problem.hess_dense(), dtype=np.float64)
             A = np.ascontiguousarray(problem.jac_dense(), dtype=np.float64).reshape(self.m, self.n)
             q, b = _lib.as_f64(problem.q), _lib.as_f64(problem.b)

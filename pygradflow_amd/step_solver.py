@@ -71,6 +71,41 @@ class _Handle:
 POOL = _HandlePool()
 
 
+def _sample_sum(arr):
+    """Cheap content fingerprint of an array (at most ~4096 strided entries)."""
+    if arr is None:
+        return 0.0
+    if sps.issparse(arr):
+        arr = arr.data
+    flat = np.asarray(arr).ravel()
+    if flat.size == 0:
+        return 0.0
+    step = max(1, flat.size // 4096)
+    return float(flat[::step].sum()) + float(flat[-1])
+
+
+def residency_key(problem):
+    """Identity under which a constant-derivative problem's H, J (and q, b) stay resident in
+    HBM: a token pinned to the problem object (so that an id cannot be recycled) PLUS a content
+    fingerprint of its arrays -- a problem whose Q / A / q / b are modified in place keeps its
+    token but not its fingerprint, and is uploaded again instead of silently reusing the stale
+    matrices.  Invalidation rule: replace the arrays, or change their entries; both
+    are noticed unless a change cancels exactly in the strided sample sums."""
+    token = getattr(problem, "_pgf_token", None)
+    if token is None:
+        token = object()
+        try:
+            problem._pgf_token = token
+        except Exception:
+            return None
+    fp = tuple(_sample_sum(getattr(problem, nm, None)) for nm in ("Q", "A", "q", "b"))
+    return (token, fp)
+
+
+def same_key(a, b):
+    return a is not None and b is not None and a[0] is b[0] and a[1] == b[1]
+
+
 def _dense_f64(mat, shape):
     if mat is None:
         return np.zeros(shape, dtype=np.float64)
@@ -286,17 +321,11 @@ class HipStepSolver:
             # identity cannot be recycled
             key = None
             if getattr(self.problem, "pgf_constant_derivs", False):
-                key = getattr(self.problem, "_pgf_token", None)
-                if key is None:
-                    key = object()
-                    try:
-                        self.problem._pgf_token = key
-                    except Exception:
-                        key = None
-            if self.sparse and (key is None or hd.derivs_key is not key):
+                key = residency_key(self.problem)
+            if self.sparse and not same_key(key, hd.derivs_key):
                 self._push_sparse_derivs()
                 hd.derivs_key = key
-            elif key is None or hd.derivs_key is not key:
+            elif not same_key(key, hd.derivs_key):
                 if self._csr_upload_pays():
                     self._push_csr_derivs()
                 else:

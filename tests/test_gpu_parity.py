@@ -774,3 +774,25 @@ def test_unstable_pivot_is_refined_or_handed_to_the_pivoted_lu(pgf, eps, expect)
     x, y = dn.point()
     assert G.rel_err(x, -s[:n]) <= 1e-9
     dn.close()
+
+
+def test_in_place_modified_problem_is_uploaded_again(pgf):
+    """HBM residency of constant H, J is keyed on the problem object AND a content fingerprint
+    (ADVICE r1): modifying Q in place must not reuse the stale device copy."""
+    from pygradflow_amd import problems
+
+    n, m = 64, 16
+    prob = problems.dense_qp(n, m, seed=5)
+    dn = pgf.DeviceNewton(prob, "Full", np.zeros(n), np.zeros(m), 1.0, 1.0)
+    dn.step()
+    x1, _ = dn.point()
+    dn.close()
+    prob.Q[np.diag_indices(n)] += 3.0  # same object, same token, new content
+    dn = pgf.DeviceNewton(prob, "Full", np.zeros(n), np.zeros(m), 1.0, 1.0)
+    dn.step()
+    x2, _ = dn.point()
+    dn.close()
+    ref = O.NewtonOracle(prob, "Full", np.zeros(n), np.zeros(m), 1.0, 1.0)
+    xr, _, _ = ref.step(np.zeros(n), np.zeros(m))
+    assert G.rel_err(x2, xr) <= TOL
+    assert G.rel_err(x1, xr) > 1e-3  # the step really depends on the change
