@@ -37,8 +37,8 @@
 #define C_LD 66    // LDS row stride of 64-column tiles: conflict-free MFMA fragment reads
 #define C_WLD 18
 #define CH_ROWS 256
-// M[256][66] | Wt[64][18] | D[64] | 1/D[64] | flag
-#define CH_SMEM (CH_ROWS * C_LD * 8 + 64 * C_WLD * 8 + 2 * 64 * 8 + 16)
+// M[256][66] | Wt[2][64][18] | D[64] | 1/D[64] | flag
+#define CH_SMEM (CH_ROWS * C_LD * 8 + 2 * 64 * C_WLD * 8 + 2 * 64 * 8 + 16)
 
 // ------------------------------------------------------------------ TS x TS tile product
 // One 16 x 16 MFMA tile per wavefront of a (TS / 16)^2-wavefront workgroup:
@@ -430,7 +430,7 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
                                            long long *__restrict__ dbg) {
   double(*M)[C_LD] = reinterpret_cast<double(*)[C_LD]>(smem);
   double(*Wt)[C_WLD] = reinterpret_cast<double(*)[C_WLD]>(smem + CH_ROWS * C_LD * 8);
-  double *dD = reinterpret_cast<double *>(smem + CH_ROWS * C_LD * 8 + 64 * C_WLD * 8);
+  double *dD = reinterpret_cast<double *>(smem + CH_ROWS * C_LD * 8 + 2 * 64 * C_WLD * 8);
   double *dI = dD + 64;
   int &s_bad = *reinterpret_cast<int *>(dI + 64);
   constexpr int NT = 64 * NW;  // NW = 16 or 8 wavefronts (8: 256 registers per lane)
@@ -488,33 +488,57 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
     __syncthreads();
     CH_STAMP();  // stack loaded
 
-    // ---- 64-column panel, four 16-column steps.  Critical path = wavefront 0; the rows below
-    // the tile follow one step behind on wavefronts 1..3 (64 rows each); MFMA updates on all.
+    // ---- 64-column panel, four 16-column steps.  Critical path = wavefront 0 (a+); the rows
+    // below the tile follow one step behind on wavefronts 1..3 (64 rows each).  The rank-16
+    // MFMA updates are split by urgency: what the NEXT phase 1 reads -- column block sb + 1 of
+    // the diagonal tile (step sb) and column block sb of the rows below (step sb - 1) -- is
+    // updated between the two barriers of the step; every other tile waits for the idle
+    // wavefronts 4.. of the following phase 1, in the shadow of (a+).  W = L D of the diagonal
+    // rows is double buffered (Wt[sb & 1]) because of that.
+    //   update of diagonal tile (ti, tj) by step t: urgent if tj == t + 1 (phase 2 of step t),
+    //                                               else phase 1 of step t + 1;
+    //   update of lower    tile (ti, tj) by step t: urgent if tj == t + 1 (phase 2 of step t + 1),
+    //                                               else phase 1 of step t + 2.
     const int ot = ownp / 16;  // 16-row tiles below the diagonal tile
+    auto diag_tile = [&](int t, int ti, int tj) {  // step t applied to diagonal tile (ti, tj)
+      chain_tile16<C_WLD>(M, ti * 16, tj * 16, Wt + (t & 1) * 64, ti * 16, 0, tj * 16, t * 16, l15, l4);
+    };
+    auto own_tile = [&](int t, int ti, int tj) {  // step t applied to lower tile (ti, tj), ti >= 4
+      chain_tile16<C_LD>(M, ti * 16, tj * 16, M, ti * 16, t * 16, tj * 16, t * 16, l15, l4);
+    };
     for (int sb = 0; sb < 4; ++sb) {
-      if (wave == 0) chain_a_plus(M, Wt, dD, dI, s_bad, lane, sb, ncol);
-      else if (wave <= 3 && sb > 0 && 64 * (wave - 1) < own) chain_b_own(M, 64 * wave + lane, sb - 1, lane);
+      if (wave == 0) {
+        chain_a_plus(M, Wt + (sb & 1) * 64, dD, dI, s_bad, lane, sb, ncol);
+      } else if (wave <= 3) {
+        if (sb > 0 && 64 * (wave - 1) < own) chain_b_own(M, 64 * wave + lane, sb - 1, lane);
+      } else {
+        // deferred tiles: diagonal (ti, tj), tj in [sb + 1, 3], of step sb - 1; lower (ti, tj),
+        // tj in [sb, 3], of step sb - 2
+        const int ndd = sb >= 1 ? (3 - sb) * (4 - sb) / 2 : 0;
+        const int ndo = sb >= 2 ? ot * (4 - sb) : 0;
+        for (int e0 = wave - 4; e0 < ndd + ndo; e0 += NW - 4) {
+          if (e0 < ndd) {
+            int e = e0, tj = sb + 1;
+            while (e >= 4 - tj) {
+              e -= 4 - tj;
+              ++tj;
+            }
+            diag_tile(sb - 1, tj + e, tj);
+          } else {
+            const int e = e0 - ndd;
+            own_tile(sb - 2, 4 + e % ot, sb + e / ot);
+          }
+        }
+      }
       __syncthreads();
       if (s == 0) CH_STAMP();  // phase 1 of step sb
-      // diagonal tile: (ti, tj), tj in (sb, 3], ti in [tj, 3], step sb;
-      // rows below:    (ti, tj), tj in [sb, 3], ti in [4, 4 + ot), step sb - 1
-      const int nd = (3 - sb) * (4 - sb) / 2;
-      const int no = sb > 0 ? ot * (4 - sb) : 0;
-      for (int e0 = wave; e0 < nd + no; e0 += NW) {
-        if (e0 < nd) {
-          int e = e0, tj = sb + 1;
-          while (e >= 4 - tj) {
-            e -= 4 - tj;
-            ++tj;
-          }
-          const int ti = tj + e;
-          chain_tile16<C_WLD>(M, ti * 16, tj * 16, Wt, ti * 16, 0, tj * 16, sb * 16, l15, l4);
-        } else {
-          const int e = e0 - nd;
-          const int tj = sb + e / ot, ti = 4 + e % ot;
-          chain_tile16<C_LD>(M, ti * 16, tj * 16, M, ti * 16, (sb - 1) * 16, tj * 16, (sb - 1) * 16,
-                             l15, l4);
-        }
+      // urgent tiles: diagonal (ti, sb + 1), ti in [sb + 1, 3], of step sb; lower (ti, sb) of
+      // step sb - 1
+      const int nud = 3 - sb;
+      const int nuo = sb >= 1 ? ot : 0;
+      for (int e0 = wave; e0 < nud + nuo; e0 += NW) {
+        if (e0 < nud) diag_tile(sb, sb + 1 + e0, sb + 1);
+        else own_tile(sb - 1, 4 + (e0 - nud), sb);
       }
       __syncthreads();
     }
