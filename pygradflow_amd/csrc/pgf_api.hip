@@ -778,8 +778,39 @@ int pgf_linear_solve(pgf_handle h, const double *rhs, int trans, double *sol) {
   if (!h) return PGF_INVALID;
   int rc;
   if ((rc = check_ready(h))) return rc;
+  if (h->sparse) {
+    // banded mode: the system keeps its full size n + m (an active variable is an identity
+    // row), so rhs / sol have n + m entries in the order [variables; constraints]; entries of
+    // active variables pass through (sol = rhs there)
+    const int Nf = h->n + h->m;
+    if (Nf && (!rhs || !sol)) return fail(h, PGF_INVALID, "null argument");
+    (void)hipSetDevice(h->device);
+    if ((rc = up(h, h->rhs, rhs, (size_t)Nf * sizeof(double)))) return rc;
+    sp_launch_permute(h->stream, h->sp, Nf, h->rhs, h->sp.brhs, 0);
+    if (h->sp.bw <= 8 && !getenv("PGF_BAND_SEQ")) {
+      // cyclic reduction keeps the assembled band intact: (re)assemble only when stale
+      if (!h->fac.factored) sp_launch_assemble(h->stream, h->sp, h->n, h->m, h->mask, h->lamb, h->delta);
+      sp_launch_bcr_solve(h->stream, h->sp, Nf, h->fac.flags);
+    } else {
+      if (!h->fac.factored) {
+        sp_launch_assemble(h->stream, h->sp, h->n, h->m, h->mask, h->lamb, h->delta);
+        sp_launch_factor(h->stream, h->sp, Nf, h->fac.flags);  // forward-substitutes brhs on the way
+      } else {
+        sp_launch_fwdsolve(h->stream, h->sp, Nf);
+      }
+      sp_launch_backsolve(h->stream, h->sp, Nf);
+    }
+    HIPCHK(h, hipMemcpyAsync(h->fac.h_flags, h->fac.flags, 4 * sizeof(int), hipMemcpyDeviceToHost,
+                             h->stream));
+    sp_launch_permute(h->stream, h->sp, Nf, h->sp.brhs, h->sol, 1);
+    if ((rc = down(h, sol, h->sol, (size_t)Nf * sizeof(double)))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->fac.h_flags[0]) return fail(h, PGF_SINGULAR, "zero or non-finite pivot in the banded KKT factorisation");
+    h->fac.n_neg = h->fac.h_flags[1];
+    h->fac.factored = true;
+    return PGF_OK;
+  }
   if (h->N && (!rhs || !sol)) return fail(h, PGF_INVALID, "null argument");
-  if (h->sparse) return fail(h, PGF_NOT_READY, "pgf_linear_solve: dense mode only");
   (void)hipSetDevice(h->device);
   if (!h->fac.factored) {
     if ((rc = factor_async(h, false))) return rc;

@@ -30,6 +30,9 @@ void sp_launch_assemble(hipStream_t s, const SparseDev &sp, int n, int m, const 
                         double lamb, double delta);
 void sp_launch_rhs(hipStream_t s, const SparseDev &sp, int n, int m, const uint8_t *mask,
                    const double *F, const double *b0full, double fact, double *Hb0, double *Jb0);
+// out[pos[i]] = in[i] (gather == 0) or out[i] = in[pos[i]] (gather != 0)
+void sp_launch_permute(hipStream_t s, const SparseDev &sp, int N, const double *in, double *out,
+                       int gather);
 void sp_launch_factor(hipStream_t s, const SparseDev &sp, int N, int *flags);
 void sp_launch_bcr_solve(hipStream_t s, const SparseDev &sp, int N, int *flags);
 void sp_launch_fwdsolve(hipStream_t s, const SparseDev &sp, int N);

@@ -251,6 +251,15 @@ __global__ __launch_bounds__(64) void k_band_backsolve(const double *__restrict_
   }
 }
 
+// full-length vector <-> permuted band order (LinearSolver.solve against the banded factor)
+__global__ void k_band_permute(int N, const int *__restrict__ pos, const double *__restrict__ in,
+                               double *__restrict__ out, int gather) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  if (gather) out[i] = in[pos[i]];
+  else out[pos[i]] = in[i];
+}
+
 // ---------------------------------------------------------------- step update (a9, a15, a16)
 __global__ __launch_bounds__(256) void k_band_step_update(
     int n, int m, const int *__restrict__ pos, const double *__restrict__ sol, double fact,
@@ -326,6 +335,11 @@ void sp_launch_rhs(hipStream_t s, const SparseDev &sp, int n, int m, const uint8
   sp_launch_spmv(s, m, sp.Jptr, sp.Jcol, sp.Jval, b0full, nullptr, 0.0, Jb0);
   hipLaunchKernelGGL(k_band_rhs, g1(n + m), dim3(256), 0, s, n, m, mask, F, b0full, Hb0, Jb0, fact,
                      sp.pos, sp.brhs);
+}
+
+void sp_launch_permute(hipStream_t s, const SparseDev &sp, int N, const double *in, double *out,
+                       int gather) {
+  if (N) hipLaunchKernelGGL(k_band_permute, g1(N), dim3(256), 0, s, N, sp.pos, in, out, gather);
 }
 
 void sp_launch_factor(hipStream_t s, const SparseDev &sp, int N, int *flags) {

@@ -205,7 +205,9 @@ class DeviceNewton:
         if self.sparse and (stale or not getattr(self._hd, "qp_loaded", False)):
             plan = BandPlan(problem.hess_sparse(), problem.jac_sparse(), self.n, self.m)
             if not plan.supported:
-                raise NotImplementedError(f"banded path: half-bandwidth {plan.bw} > {MAX_BANDWIDTH}")
+                raise NotImplementedError(
+                    f"banded path: half-bandwidth {plan.bw} > {MAX_BANDWIDTH}; use HipStepSolver "
+                    "(plugin path), which falls back to the dense factorisation")
             plan.upload(lib, h)
             hv, jv = plan.values(problem.hess_sparse(), problem.jac_sparse())
             _lib.check(lib.pgf_sparse_set_values(h, _lib.dptr(hv), _lib.dptr(jv)), h,

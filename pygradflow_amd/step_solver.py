@@ -28,6 +28,7 @@ from .linear_solver import HipLinearSolver
 from .sparse import BandPlan, MAX_BANDWIDTH
 
 DENSE_LIMIT = 20000  # n + m above which sparse derivatives take the banded path
+DENSE_MAX = 60000    # largest n + m the dense path accepts (pgf_create; 28.8 GB of KKT matrix)
 
 
 # --------------------------------------------------------------------------- handles
@@ -323,8 +324,15 @@ class HipStepSolver:
             if getattr(self.problem, "pgf_constant_derivs", False):
                 key = residency_key(self.problem)
             if self.sparse and not same_key(key, hd.derivs_key):
-                self._push_sparse_derivs()
-                hd.derivs_key = key
+                if self._push_sparse_derivs():
+                    hd.derivs_key = key
+                else:
+                    # the pattern is not banded enough for the banded kernels: take the dense
+                    # path (CSR upload, densified on the device) -- the reference's SuperLU takes
+                    # any pattern (lu_solver.py:14), so must this solver, as long as the dense
+                    # KKT matrix fits
+                    self._switch_to_dense()
+                    return self._push_state()
             elif not same_key(key, hd.derivs_key):
                 if self._csr_upload_pays():
                     self._push_csr_derivs()
@@ -371,7 +379,23 @@ class HipStepSolver:
             jp.ctypes.data_as(ip), ji.ctypes.data_as(ip), _lib.dptr(jv))
         _lib.check(rc, hd.h, "pgf_set_derivs_csr")
 
+    def _switch_to_dense(self):
+        if self.n + self.m > DENSE_MAX:
+            raise NotImplementedError(
+                f"sparse problem with half-bandwidth > {MAX_BANDWIDTH} after RCM and "
+                f"n + m = {self.n + self.m} > {DENSE_MAX}: neither the banded nor the dense path "
+                "can take it")
+        device = self._hd.device
+        POOL.release(self._hd)
+        self.sparse = False
+        self._hd = POOL.acquire(self.n, self.m, device, sparse=False)
+        self._outer_sent = False
+        self._mask_dirty = True
+        self._derivs_dirty = True
+
     def _push_sparse_derivs(self):
+        """Upload pattern (once) and values; False if the pattern is too wide for the banded
+        kernels."""
         hd = self._hd
         hess = sps.csr_matrix(self._hess)
         jac = sps.csr_matrix(self._jac) if self.m else sps.csr_matrix((0, self.n))
@@ -379,9 +403,7 @@ class HipStepSolver:
             if hd.plan is None:
                 plan = BandPlan(hess, jac, self.n, self.m)
                 if not plan.supported:
-                    raise NotImplementedError(
-                        f"banded path supports half-bandwidth <= {MAX_BANDWIDTH} after RCM "
-                        f"(got {plan.bw}); this problem needs the general sparse path")
+                    return False
                 plan.upload(self._lib, hd.h)
                 hd.plan = plan
             try:
@@ -393,6 +415,7 @@ class HipStepSolver:
                 hd.plan = None  # pattern changed: re-plan once
         _lib.check(self._lib.pgf_sparse_set_values(hd.h, _lib.dptr(hv), _lib.dptr(jv)), hd.h,
                    "pgf_sparse_set_values")
+        return True
 
     def reduced_dims(self):
         if self.sparse:
@@ -412,6 +435,19 @@ class HipStepSolver:
         if N:
             _lib.check(self._lib.pgf_get_kkt(self._hd.h, _lib.dptr(K), N), self._hd.h, "pgf_get_kkt")
         return K
+
+    def _host_reduced_kkt(self):
+        """Reduced KKT matrix as scipy CSR (banded mode, diagnostics only: the products of the
+        condition estimate; reference symmetric_step_solver.py:49-77)."""
+        ina = np.where(np.logical_not(self.active_set))[0]
+        lamb = 1.0 / self.dt
+        H = sps.csr_matrix(self._hess) + sps.diags([lamb], shape=(self.n, self.n))
+        Hii = sps.csr_matrix(H)[ina, :][:, ina]
+        if self.m == 0:
+            return sps.csr_matrix(Hii)
+        Ji = sps.csc_matrix(self._jac)[:, ina]
+        lower = sps.diags([-lamb / (1.0 + lamb * self.rho)], shape=(self.m, self.m))
+        return sps.bmat([[Hii, Ji.T], [Ji, lower]], format="csr")
 
     def refinement_stats(self):
         """(refinement steps, LU fallbacks, relative residual of the last checked solve) of
@@ -448,11 +484,14 @@ class HipStepSolver:
             raise StepSolverError(str(e)) from e
         self.solver = _DeviceFactorView(self)
         rcond = None
-        if getattr(params, "report_rcond", False) and not self.sparse:
+        if getattr(params, "report_rcond", False):
             from .cond_estimate import estimate_rcond
 
-            Kl = self.kkt_matrix()
-            Kfull = Kl + np.tril(Kl, -1).T
+            if self.sparse:
+                Kfull = self._host_reduced_kkt()
+            else:
+                Kl = self.kkt_matrix()
+                Kfull = Kl + np.tril(Kl, -1).T
             rcond = estimate_rcond(Kfull, self.solver, params)
         return StepResult(iterate, dx, dy, self.active_set, rcond, xn=xn, yn=yn, diff=diff.value)
 
@@ -467,9 +506,21 @@ class _DeviceFactorView:
 
     def solve(self, rhs, trans=False, initial_sol=None):
         o = self._o
-        if o.sparse:
-            raise NotImplementedError("solve against the banded factor is not exposed yet")
         rhs = _lib.as_f64(rhs)
+        if o.sparse:
+            # the banded system keeps its full size (active variables are identity rows):
+            # expand the reduced right-hand side, solve, gather the reduced solution
+            ina = np.logical_not(o.active_set)
+            ni = int(np.count_nonzero(ina))
+            if rhs.shape != (ni + o.m,):
+                raise ValueError("rhs shape mismatch")
+            full = np.zeros(o.n + o.m)
+            full[: o.n][ina] = rhs[:ni]
+            full[o.n:] = rhs[ni:]
+            out = np.empty_like(full)
+            rc = o._lib.pgf_linear_solve(o._hd.h, _lib.dptr(full), int(bool(trans)), _lib.dptr(out))
+            _lib.check(rc, o._hd.h, "pgf_linear_solve")
+            return np.concatenate([out[: o.n][ina], out[o.n:]])
         sol = np.empty_like(rhs)
         rc = o._lib.pgf_linear_solve(o._hd.h, _lib.dptr(rhs), int(bool(trans)), _lib.dptr(sol))
         _lib.check(rc, o._hd.h, "pgf_linear_solve")
