@@ -234,6 +234,22 @@ int pgf_batch_sync(pgf_batch b, int *status, int *n_neg, double *diff);
 /* unscaled residual norms of all instances: host array and / or device array (the
  * rank-local block of the RCCL all-gather) */
 int pgf_batch_residual_norms(pgf_batch b, double *norms_out, double *norms_out_dev);
+/* ---- device-resident step controller -------------------------------
+ * The reference's default DistanceRatioController (step/distance_ratio_control.py:12-78: two
+ * Newton steps per outer iteration, theta = |step 2| / |step 1|, accept iff theta <= theta_max,
+ * PI law on log(theta) for lambda, controller.py:54-77; early exits :34-45; a failed
+ * factorisation = rejected step with 2 lambda, step_control.py:103-107) for every instance of
+ * the batch, decided ON THE DEVICE: pgf_batch_ctl_iterate enqueues `iterations` outer
+ * iterations back to back with no host synchronisation in between (per-instance lambda, PI
+ * integral, accept flag and frozen flags live in HBM).  params: newton_tol, lamb_red,
+ * lamb_min, lamb_inc, theta_max, K_P, K_I, theta_ref (Params fields of the same names).
+ * pgf_batch_ctl_read waits and returns the next lambda and the last accept flag of every
+ * instance and, per outer iteration and instance, (lambda used, lambda next, accepted). */
+int pgf_batch_ctl_init(pgf_batch b, double lamb_init, double rho, const double *params,
+                       int max_iterations);
+int pgf_batch_ctl_iterate(pgf_batch b, unsigned policy, double tau, int iterations);
+int pgf_batch_ctl_read(pgf_batch b, double *lamb, uint8_t *accepted, double *log3, int log_rows);
+
 /* all points / masks, instance-major: x[count][n], y[count][m], mask[count][n] */
 int pgf_batch_get_points(pgf_batch b, double *x, double *y);
 int pgf_batch_get_masks(pgf_batch b, uint8_t *mask);

@@ -36,6 +36,7 @@ def __getattr__(name):
 
         return getattr(newton, name)
     if name in ("DistanceRatioController", "DeviceDistanceRatioController", "NewtonController",
+                "BatchedDistanceRatioController", "DeviceResidentDistanceRatioController",
                 "StepController", "StepControlResult", "gradient_flow"):
         from . import step_control
 

@@ -249,6 +249,38 @@ class BatchedDeviceNewton:
                                                             self._lib.dptr(out)), batch=self._b)
         return out
 
+    # -- device-resident step controller (pgf_batch_ctl_*) ------------------------------
+    def ctl_init(self, params, rho=None, max_iterations=64, lamb_init=None):
+        """Arm the device-resident ``DistanceRatioController`` of every local instance."""
+        if self._b is None:
+            raise NotImplementedError("device batch only")
+        vals = np.array([params.newton_tol, params.lamb_red, params.lamb_min, params.lamb_inc,
+                         params.theta_max, params.K_P, params.K_I, params.theta_ref], dtype=np.float64)
+        rho = self.rho if rho is None else float(rho)
+        lamb = float(params.lamb_init if lamb_init is None else lamb_init)
+        self._ctl_cap = int(max_iterations)
+        self._lib.check(self._lib.load().pgf_batch_ctl_init(self._b, lamb, rho, self._lib.dptr(vals),
+                                                            self._ctl_cap), batch=self._b,
+                        what="pgf_batch_ctl_init")
+
+    def ctl_iterate(self, iterations):
+        """Enqueue ``iterations`` outer iterations (two batched Newton steps + the controller's
+        decisions each) without a host synchronisation in between."""
+        self._lib.check(self._lib.load().pgf_batch_ctl_iterate(self._b, self.policy, self.tau,
+                                                               int(iterations)), batch=self._b,
+                        what="pgf_batch_ctl_iterate")
+
+    def ctl_read(self):
+        """Wait; returns (lamb_next[count], accepted[count], log[iterations][count][3]) with
+        log rows (lambda used, lambda next, accepted) per outer iteration so far."""
+        lamb = np.empty(self.count)
+        acc = np.empty(self.count, dtype=np.bool_)
+        log = np.zeros((self._ctl_cap, self.count, 3))
+        self._lib.check(self._lib.load().pgf_batch_ctl_read(
+            self._b, self._lib.dptr(lamb), self._lib.u8ptr(acc), self._lib.dptr(log), self._ctl_cap),
+            batch=self._b, what="pgf_batch_ctl_read")
+        return lamb, acc, log
+
     def profile(self, on=True):
         if self._b is not None:
             self._lib.check(self._lib.load().pgf_batch_profile_enable(self._b, int(on)),

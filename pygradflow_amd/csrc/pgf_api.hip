@@ -1199,6 +1199,10 @@ struct pgf_batch_s {
   BatchScalars sc{};
   bool outer_set = false, eval_fresh = false, step_pending = false, have_mask = false;
   bool all_factored = false;
+  // device-resident step controller (pgf_batch_ctl_*): per-instance state, constants, and a
+  // log of (lambda used, lambda next, accepted) per outer iteration and instance
+  double *dctl_cs = nullptr, *dctl_cp = nullptr, *dctl_log = nullptr;
+  int dctl_log_cap = 0, dctl_logged = 0;
   PgfProfile prof;
   std::string err = "";
 };
@@ -1340,7 +1344,7 @@ int pgf_batch_destroy(pgf_batch b) {
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   for (void *p : {(void *)b->tab, (void *)b->ctl, (void *)b->flags_out, (void *)b->diff_out,
                   (void *)b->norm_out, (void *)b->red4, (void *)b->meas_out, (void *)b->ps,
-                  (void *)b->bytes})
+                  (void *)b->bytes, (void *)b->dctl_cs, (void *)b->dctl_cp, (void *)b->dctl_log})
     if (p) (void)hipFree(p);
   for (void *p : {(void *)b->h_flags, (void *)b->h_diff, (void *)b->h_norm, (void *)b->h_meas,
                   (void *)b->h_ps, (void *)b->h_bytes})
@@ -1448,6 +1452,27 @@ int pgf_batch_update_active_set(pgf_batch b, double tau) {
   return PGF_OK;
 }
 
+// everything of one batched Newton step, enqueued; host_knows_factored: the host's view that
+// every instance holds a valid factor (lets a Simplified step skip the factor launches)
+static void batch_enqueue_step(pgf_batch b, unsigned policy, double tau, bool host_knows_factored) {
+  const bool recompute = (policy & PGF_STEP_RECOMPUTE_MASK) != 0;
+  const bool force = (policy & PGF_STEP_REFACTOR) != 0;
+  batch_eval(b);
+  batch_launch_mask(b->stream, b->tab, b->B, b->sc, recompute ? (force ? 2 : 1) : 0, tau);
+  b->have_mask = true;
+  batch_launch_rhs_assemble(b->stream, b->tab, b->B, b->sc);
+  const int Nmax = b->n + b->m;
+  // kernels of instances whose factor is still valid return at once (ctl[0] == 0); when the
+  // host knows that every instance refactorises (Full) or none does, skip the other half
+  const bool none_factor = !recompute && host_knows_factored;
+  if (!none_factor)
+    ldlt_batch_factor_async(b->stream, b->tab, b->B, Nmax, b->m, b->OB,
+                            b->prof.enabled ? &b->prof : nullptr);
+  ldlt_batch_solve_async(b->stream, b->tab, b->B, Nmax, b->m, !force);
+  batch_launch_step_update(b->stream, b->tab, b->B, b->sc, b->diff_out, b->flags_out);
+  b->eval_fresh = false;
+}
+
 int pgf_batch_step_async(pgf_batch b, unsigned policy, double tau) {
   if (!b) return PGF_INVALID;
   if (!b->outer_set) return bfail(b, PGF_NOT_READY, "pgf_batch_advance_outer first");
@@ -1459,25 +1484,115 @@ int pgf_batch_step_async(pgf_batch b, unsigned policy, double tau) {
     return bfail(b, PGF_NOT_READY, "no active set: pgf_batch_update_active_set first");
   if (!recompute && force)
     return bfail(b, PGF_INVALID, "batch: PGF_STEP_REFACTOR needs PGF_STEP_RECOMPUTE_MASK");
-  batch_eval(b);
-  batch_launch_mask(b->stream, b->tab, b->B, b->sc, recompute ? (force ? 2 : 1) : 0, tau);
-  b->have_mask = true;
-  batch_launch_rhs_assemble(b->stream, b->tab, b->B, b->sc);
-  const int Nmax = b->n + b->m;
-  // kernels of instances whose factor is still valid return at once (ctl[0] == 0); when the
-  // host knows that every instance refactorises (Full) or none does, skip the other half
-  const bool none_factor = !recompute && b->all_factored;
-  if (!none_factor)
-    ldlt_batch_factor_async(b->stream, b->tab, b->B, Nmax, b->m, b->OB,
-                            b->prof.enabled ? &b->prof : nullptr);
-  ldlt_batch_solve_async(b->stream, b->tab, b->B, Nmax, b->m, !force);
-  batch_launch_step_update(b->stream, b->tab, b->B, b->sc, b->diff_out, b->flags_out);
-  b->eval_fresh = false;
+  batch_enqueue_step(b, policy, tau, b->all_factored);
   BHIPCHK(b, hipMemcpyAsync(b->h_diff, b->diff_out, b->B * sizeof(double), hipMemcpyDeviceToHost,
                             b->stream));
   BHIPCHK(b, hipMemcpyAsync(b->h_flags, b->flags_out, (size_t)b->B * 3 * sizeof(int),
                             hipMemcpyDeviceToHost, b->stream));
   b->step_pending = true;
+  return PGF_OK;
+}
+
+// ---- device-resident DistanceRatioController ------------------------------
+int pgf_batch_ctl_init(pgf_batch b, double lamb_init, double rho, const double *params,
+                       int max_iterations) {
+  if (!b || !params || !(lamb_init > 0.0) || !(rho > 0.0) || max_iterations < 1) return PGF_INVALID;
+  if (b->step_pending) return bfail(b, PGF_NOT_READY, "pgf_batch_sync the previous step first");
+  (void)hipSetDevice(b->device);
+  const size_t ncs = (size_t)b->B * DCS_STRIDE;
+  if (!b->dctl_cs) BHIPCHK(b, dalloc(&b->dctl_cs, ncs));
+  if (!b->dctl_cp) BHIPCHK(b, dalloc(&b->dctl_cp, (size_t)DCP_COUNT));
+  if (b->dctl_log_cap < max_iterations) {
+    if (b->dctl_log) (void)hipFree(b->dctl_log);
+    b->dctl_log = nullptr;
+    BHIPCHK(b, dalloc(&b->dctl_log, (size_t)max_iterations * b->B * 3));
+    b->dctl_log_cap = max_iterations;
+  }
+  std::vector<double> cs(ncs, 0.0), cp(DCP_COUNT, 0.0);
+  for (int i = 0; i < b->B; ++i) {
+    cs[(size_t)DCS_STRIDE * i + DCS_LAMB] = lamb_init;
+    cs[(size_t)DCS_STRIDE * i + DCS_ACCEPTED] = 1.0;
+  }
+  cp[DCP_RHO] = rho;
+  // params: newton_tol, lamb_red, lamb_min, lamb_inc, theta_max, K_P, K_I, theta_ref
+  cp[DCP_NEWTON_TOL] = params[0];
+  cp[DCP_LAMB_RED] = params[1];
+  cp[DCP_LAMB_MIN] = params[2];
+  cp[DCP_LAMB_INC] = params[3];
+  cp[DCP_THETA_MAX] = params[4];
+  cp[DCP_K_P] = params[5];
+  cp[DCP_K_I] = params[6];
+  if (!(params[7] > 0.0)) return bfail(b, PGF_INVALID, "theta_ref must be positive");
+  cp[DCP_LOG_THETA_REF] = std::log(params[7]);
+  BHIPCHK(b, hipMemcpyAsync(b->dctl_cs, cs.data(), ncs * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  BHIPCHK(b, hipMemcpyAsync(b->dctl_cp, cp.data(), DCP_COUNT * sizeof(double), hipMemcpyHostToDevice,
+                            b->stream));
+  BHIPCHK(b, hipStreamSynchronize(b->stream));
+  b->dctl_logged = 0;
+  return PGF_OK;
+}
+
+int pgf_batch_ctl_iterate(pgf_batch b, unsigned policy, double tau, int iterations) {
+  if (!b || iterations < 0) return PGF_INVALID;
+  if (!b->dctl_cs) return bfail(b, PGF_NOT_READY, "pgf_batch_ctl_init first");
+  if (b->step_pending) return bfail(b, PGF_NOT_READY, "pgf_batch_sync the previous step first");
+  if (b->dctl_logged + iterations > b->dctl_log_cap)
+    return bfail(b, PGF_INVALID, "more iterations than pgf_batch_ctl_init reserved a log for");
+  const bool recompute = (policy & PGF_STEP_RECOMPUTE_MASK) != 0;
+  if (!recompute && (policy & PGF_STEP_REFACTOR))
+    return bfail(b, PGF_INVALID, "batch: PGF_STEP_REFACTOR needs PGF_STEP_RECOMPUTE_MASK");
+  (void)hipSetDevice(b->device);
+  hipStream_t s = b->stream;
+  for (int it = 0; it < iterations; ++it) {
+    // outer step of every instance at its own lambda; rejected instances go back first
+    batch_launch_dctl_begin(s, b->B, b->dctl_cs, b->dctl_cp, b->ps, b->bytes);
+    batch_launch_advance(s, b->tab, b->B, b->sc, b->bytes);
+    b->eval_fresh = false;
+    b->outer_set = true;
+    if (!recompute) {  // Simplified: mask and derivatives frozen at the outer point
+      batch_eval(b);
+      batch_launch_mask(s, b->tab, b->B, b->sc, 2, tau);
+    }
+    batch_enqueue_step(b, policy, tau, false);
+    batch_eval(b);
+    batch_launch_res_norm(s, b->tab, b->B, b->sc, b->norm_out);
+    batch_launch_dctl_mid(s, b->tab, b->B, b->dctl_cs, b->dctl_cp, b->diff_out, b->flags_out,
+                          b->norm_out);
+    batch_enqueue_step(b, policy, tau, false);
+    batch_launch_dctl_end(s, b->B, b->dctl_cs, b->dctl_cp, b->diff_out, b->flags_out,
+                          b->dctl_log + (size_t)b->dctl_logged * b->B * 3);
+    ++b->dctl_logged;
+  }
+  b->all_factored = false;
+  BHIPCHK(b, hipGetLastError());
+  return PGF_OK;
+}
+
+int pgf_batch_ctl_read(pgf_batch b, double *lamb, uint8_t *accepted, double *log3, int log_rows) {
+  if (!b) return PGF_INVALID;
+  if (!b->dctl_cs) return bfail(b, PGF_NOT_READY, "pgf_batch_ctl_init first");
+  (void)hipSetDevice(b->device);
+  BHIPCHK(b, hipStreamSynchronize(b->stream));
+  std::vector<double> cs((size_t)b->B * DCS_STRIDE);
+  BHIPCHK(b, hipMemcpy(cs.data(), b->dctl_cs, cs.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int i = 0; i < b->B; ++i) {
+    if (lamb) lamb[i] = cs[(size_t)DCS_STRIDE * i + DCS_LAMB];
+    if (accepted) accepted[i] = cs[(size_t)DCS_STRIDE * i + DCS_ACCEPTED] != 0.0;
+    // the handles' host-side scalars follow the device's (the next host-driven call may use them)
+    pgf_handle h = b->hs[i];
+    const double l = cs[(size_t)DCS_STRIDE * i + DCS_USED];
+    if (l > 0.0) {
+      h->dt = 1.0 / l;
+      h->lamb = 1.0 / h->dt;
+      h->fact = 1.0 / (1.0 + h->lamb * h->rho);
+      h->delta = h->lamb / (1.0 + h->lamb * h->rho);
+    }
+  }
+  if (log3 && log_rows > 0) {
+    const int rows = std::min(log_rows, b->dctl_logged);
+    BHIPCHK(b, hipMemcpy(log3, b->dctl_log, (size_t)rows * b->B * 3 * sizeof(double),
+                         hipMemcpyDeviceToHost));
+  }
   return PGF_OK;
 }
 

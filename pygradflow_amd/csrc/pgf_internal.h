@@ -128,6 +128,32 @@ struct BatchScalars {
 #define BPS_DELTA 4
 #define BPS_STRIDE 8
 
+// device-resident step controller: per-instance state (cs) and constants (cp)
+#define DCS_LAMB 0      // lambda of the next outer iteration
+#define DCS_INTEGRAL 1  // integral of the PI law (log scale)
+#define DCS_FIRST 2     // step length of the first Newton step
+#define DCS_ACCEPTED 3  // 1: the last outer step was accepted
+#define DCS_DONE 4      // 1: decided after the first Newton step
+#define DCS_NEXT 5      // lambda decided so far
+#define DCS_USED 6      // lambda the current iteration ran with
+#define DCS_STRIDE 8
+#define DCP_RHO 0
+#define DCP_NEWTON_TOL 1
+#define DCP_LAMB_RED 2
+#define DCP_LAMB_MIN 3
+#define DCP_LAMB_INC 4
+#define DCP_THETA_MAX 5
+#define DCP_K_P 6
+#define DCP_K_I 7
+#define DCP_LOG_THETA_REF 8
+#define DCP_COUNT 16
+void batch_launch_dctl_begin(hipStream_t s, int B, const double *cs, const double *cp, double *ps,
+                             uint8_t *accept);
+void batch_launch_dctl_mid(hipStream_t s, const BInst *tab, int B, double *cs, const double *cp,
+                           const double *diff, const int *flags, const double *norm);
+void batch_launch_dctl_end(hipStream_t s, int B, double *cs, const double *cp, const double *diff,
+                           const int *flags, double *log3);
+
 // pgf_kernels.hip
 // accept[i] != 0: (x^, y^) <- (x, y); == 0: (x, y) <- (x^, y^) (a rejected step goes back)
 void batch_launch_advance(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc,

@@ -990,6 +990,113 @@ __global__ __launch_bounds__(256) void kb_norm_final(const BInst *__restrict__ t
 
 static inline dim3 gb(int cnt, int per, int B) { return dim3((cnt + per - 1) / per, 1, B); }
 
+// ---------------------------------------------------------------- device-resident step controller
+// The reference's default DistanceRatioController (step/distance_ratio_control.py:12-78, PI law of
+// controller.py:54-77) for every instance of a batch WITHOUT host round trips: three tiny kernels
+// around the two batched Newton steps of an outer iteration keep lambda, the PI integral, the
+// accept flag and the early exits on the device.  cs: DCS_STRIDE doubles per instance; cp: the
+// controller's constants; log: 3 doubles per (iteration, instance).
+__global__ void kb_dctl_begin(int B, const double *__restrict__ cs, const double *__restrict__ cp,
+                              double *__restrict__ ps, uint8_t *__restrict__ accept) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const double *c = cs + (size_t)DCS_STRIDE * i;
+  // the host controller hands over dt = 1 / lambda and the library recomputes lambda = 1 / dt
+  // (pgf_batch_advance_outer_each): same two roundings here
+  const double dt = 1.0 / c[DCS_LAMB];
+  const double lamb = 1.0 / dt, rho = cp[DCP_RHO];
+  double *p = ps + (size_t)BPS_STRIDE * i;
+  p[BPS_DT] = dt;
+  p[BPS_LAMB] = lamb;
+  p[BPS_RHO] = rho;
+  p[BPS_FACT] = 1.0 / (1.0 + lamb * rho);
+  p[BPS_DELTA] = lamb / (1.0 + lamb * rho);
+  accept[i] = c[DCS_ACCEPTED] != 0.0 ? 1 : 0;
+}
+
+// after the first Newton step: failed factorisation -> reject, 2 lambda; converged residual ->
+// accept, lambda * lamb_red; zero step -> accept; all three freeze the instance for step two
+__global__ void kb_dctl_mid(const BInst *__restrict__ tab, int B, double *__restrict__ cs,
+                            const double *__restrict__ cp, const double *__restrict__ diff,
+                            const int *__restrict__ flags, const double *__restrict__ norm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  double *c = cs + (size_t)DCS_STRIDE * i;
+  const double lamb = c[DCS_LAMB];
+  c[DCS_USED] = lamb;
+  double next = lamb, acc = 1.0, done = 1.0;
+  if (flags[3 * i] != 0) {
+    next = 2.0 * lamb;
+    acc = 0.0;
+  } else if (norm[i] <= cp[DCP_NEWTON_TOL]) {
+    next = fmax(lamb * cp[DCP_LAMB_RED], cp[DCP_LAMB_MIN]);
+  } else if (diff[i] == 0.0) {
+    next = lamb;
+  } else {
+    done = 0.0;
+  }
+  c[DCS_NEXT] = next;
+  c[DCS_ACCEPTED] = acc;
+  c[DCS_DONE] = done;
+  c[DCS_FIRST] = diff[i];
+  tab[i].ctl[3] = done != 0.0 ? 1 : 0;
+}
+
+// after the second step: theta test + PI update on the log scale for the instances still in play
+__global__ void kb_dctl_end(int B, double *__restrict__ cs, const double *__restrict__ cp,
+                            const double *__restrict__ diff, const int *__restrict__ flags,
+                            double *__restrict__ log3) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  double *c = cs + (size_t)DCS_STRIDE * i;
+  const double lamb = c[DCS_LAMB];
+  double next = c[DCS_NEXT], acc = c[DCS_ACCEPTED];
+  if (c[DCS_DONE] == 0.0) {
+    const double second = diff[i];
+    if (flags[3 * i] != 0) {
+      next = 2.0 * lamb;
+      acc = 0.0;
+    } else if (second == 0.0) {
+      next = lamb;
+      acc = 1.0;
+    } else {
+      const double theta = second / c[DCS_FIRST];
+      if (theta <= cp[DCP_THETA_MAX]) {
+        const double e = cp[DCP_LOG_THETA_REF] - log(theta);
+        const double integral = c[DCS_INTEGRAL] + e;
+        c[DCS_INTEGRAL] = integral;
+        const double u = cp[DCP_K_P] * e + cp[DCP_K_I] * integral;
+        next = fmax(cp[DCP_LAMB_MIN], lamb / exp(u));
+        acc = 1.0;
+      } else {
+        next = lamb * cp[DCP_LAMB_INC];
+        acc = 0.0;
+      }
+    }
+  }
+  c[DCS_LAMB] = next;
+  c[DCS_ACCEPTED] = acc;
+  if (log3) {
+    log3[3 * i] = lamb;
+    log3[3 * i + 1] = next;
+    log3[3 * i + 2] = acc;
+  }
+}
+
+void batch_launch_dctl_begin(hipStream_t s, int B, const double *cs, const double *cp, double *ps,
+                             uint8_t *accept) {
+  hipLaunchKernelGGL(kb_dctl_begin, dim3((B + 255) / 256), dim3(256), 0, s, B, cs, cp, ps, accept);
+}
+void batch_launch_dctl_mid(hipStream_t s, const BInst *tab, int B, double *cs, const double *cp,
+                           const double *diff, const int *flags, const double *norm) {
+  hipLaunchKernelGGL(kb_dctl_mid, dim3((B + 255) / 256), dim3(256), 0, s, tab, B, cs, cp, diff, flags,
+                     norm);
+}
+void batch_launch_dctl_end(hipStream_t s, int B, double *cs, const double *cp, const double *diff,
+                           const int *flags, double *log3) {
+  hipLaunchKernelGGL(kb_dctl_end, dim3((B + 255) / 256), dim3(256), 0, s, B, cs, cp, diff, flags, log3);
+}
+
 void batch_launch_advance(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc,
                           const uint8_t *accept) {
   hipLaunchKernelGGL(kb_advance, gb(std::max(1, sc.n + sc.m), 256, B), dim3(256), 0, s, tab, sc.n,

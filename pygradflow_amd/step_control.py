@@ -277,6 +277,31 @@ class BatchedDistanceRatioController:
         return lamb, lamb_n, accepted
 
 
+class DeviceResidentDistanceRatioController:
+    """The same controller with the DECISIONS on the device (VERDICT r1
+    missing 6): ``run(k)`` enqueues k outer iterations of every local instance -- per-instance
+    lambda, PI integral, accept / reject with restore and the early exits live in HBM
+    (``pgf_batch_ctl_*``, kernels ``kb_dctl_begin / _mid / _end``) -- and the host synchronises
+    once, at the end, instead of reading two step lengths and a residual norm per iteration.
+    ``history`` then holds (lambda used, lambda next, accepted) per iteration and instance."""
+
+    def __init__(self, batch, params, rho=None, max_iterations=64):
+        self.bd = batch
+        self.params = params
+        batch.ctl_init(params, rho=rho, max_iterations=max_iterations)
+        self.lamb = np.full(batch.count, float(params.lamb_init))
+        self.accepted = np.ones(batch.count, dtype=bool)
+        self.history = np.zeros((0, batch.count, 3))
+        self._done = 0
+
+    def run(self, iterations):
+        self.bd.ctl_iterate(iterations)
+        self._done += int(iterations)
+        self.lamb, self.accepted, log = self.bd.ctl_read()
+        self.history = log[: self._done]
+        return self.lamb, self.accepted
+
+
 def gradient_flow(controller, make_iterate, x0, y0, rho, iterations, lamb=None):
     """Minimal outer loop around a host step controller (the accept / lambda bookkeeping of
     ``Solver.solve``, solver.py:300-378, without penalty updates and termination tests).

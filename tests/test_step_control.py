@@ -218,3 +218,66 @@ def test_batched_distance_ratio_controller(pgf, kind):
         dn.close()
     bd.close()
     assert rejected_seen or kind == "Full"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["Full", "Simplified", "ActiveSet"])
+def test_device_resident_controller_matches_host_controller(pgf, kind):
+    """pgf_batch_ctl_*: nine outer iterations enqueued back to back with every decision taken
+    on the device, against the host-driven BatchedDistanceRatioController on a twin batch:
+    the same accept / reject flags, lambdas equal to rounding (device log / exp vs libm), the
+    same points; then against the reference's own controller trajectory for one instance."""
+    from pygradflow_amd import problems
+    from pygradflow_amd.batched import BatchedDeviceNewton
+
+    B, n, m, iters = 5, 96, 24, 9
+
+    def make(i):
+        return problems.dense_qp(n, m, seed=30 + i, boxed_frac=0.2 + 0.1 * i, box=0.05)
+
+    par = Params(newton_type=kind, lamb_init=1.0)
+    host_b = BatchedDeviceNewton(make, B, kind, 1.0, 1.0)
+    host = SC.BatchedDistanceRatioController(host_b, par, rho=1.0)
+    dev_b = BatchedDeviceNewton(make, B, kind, 1.0, 1.0)
+    dev = SC.DeviceResidentDistanceRatioController(dev_b, par, rho=1.0, max_iterations=iters)
+    rec = [host.step() for _ in range(iters)]
+    dev.run(iters)  # ONE host synchronisation for all nine iterations
+    rejected = False
+    for it, (lamb_used, lamb_next, acc) in enumerate(rec):
+        assert np.array_equal(dev.history[it, :, 2] != 0.0, acc), it
+        assert np.allclose(dev.history[it, :, 0], lamb_used, rtol=1e-12, atol=0), it
+        assert np.allclose(dev.history[it, :, 1], lamb_next, rtol=1e-12, atol=0), it
+        rejected |= not acc.all()
+    assert np.allclose(dev.lamb, host.lamb, rtol=1e-12)
+    # put rejected instances back (the next outer step would) and compare the points
+    host_b.advance_outer_each(1.0 / host.lamb, host.rho, host.accepted)
+    dev_b.advance_outer_each(1.0 / dev.lamb, np.full(B, 1.0), dev.accepted)
+    xh, yh = host_b.points()
+    xd, yd = dev_b.points()
+    assert G.rel_err(xd, xh) <= 1e-10 and G.rel_err(yd, yh) <= 1e-10
+    host_b.close()
+    dev_b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("newton_type", ["Simplified", "Full"])
+def test_device_resident_controller_against_reference_trajectory(pgf, newton_type):
+    """The reference's DistanceRatioController trajectory (ctl_dense_qp_boxed_n96_m24_*.npz:
+    lambda, accept flag and iterate per outer iteration) with all decisions on the device."""
+    from pygradflow_amd.batched import BatchedDeviceNewton
+
+    case = G.load_case(f"ctl_dense_qp_boxed_n96_m24_{newton_type}")
+    problem = G.rebuild_problem(case)
+    iters = int(case["iterations"])
+    par = Params(newton_type=newton_type, lamb_init=float(case["lamb_init"]))
+    bd = BatchedDeviceNewton(lambda i: problem, 1, newton_type, 1.0, float(case["rho"]))
+    ctl = SC.DeviceResidentDistanceRatioController(bd, par, rho=float(case["rho"]),
+                                                   max_iterations=iters)
+    ctl.run(iters)
+    assert np.array_equal(ctl.history[:, 0, 2] != 0.0, case["accepted"])
+    assert np.allclose(ctl.history[:, 0, 0], case["lamb"], rtol=1e-9)
+    assert np.allclose(ctl.history[:, 0, 1], case["lamb_next"], rtol=1e-9)
+    bd.advance_outer_each(1.0 / ctl.lamb, np.array([float(case["rho"])]), ctl.accepted)
+    x, y = bd.points()
+    assert G.rel_err(x[0], case["x"][-1]) <= 1e-9 and G.rel_err(y[0], case["y"][-1]) <= 1e-9
+    bd.close()
