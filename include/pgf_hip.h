@@ -285,6 +285,12 @@ int pgf_ls_destroy(pgf_ls_handle ls);
 int pgf_bench_update(int N, int KB, int variant, int reps, int device, double *ms_out,
                      double *flops_out);
 
+/* out <- K v: the reduced KKT matrix of the current active set applied to a host vector of
+ * length N = |I| + m on the device, from H, J and the mask (symmetric: K' v is the same).
+ * These are the `mat @ x` / `mat.T @ x` products of the reference's ConditionEstimator
+ * (step/cond_estimate.py:60-82); dense mode only. */
+int pgf_kkt_apply(pgf_handle h, const double *v, double *out);
+
 /* ---- accuracy guard of the dense path ---------------------------------------------- */
 /* The reference factorises the reduced KKT matrix with a PIVOTED sparse LU (SuperLU through
  * scipy.sparse.linalg.splu, linear_solver/lu_solver.py:14) and therefore stays accurate when

@@ -94,6 +94,7 @@ SIGNATURES = {
     "pgf_batch_ctl_init": (C.c_int, [_h, C.c_double, C.c_double, _dp, C.c_int]),
     "pgf_batch_ctl_iterate": (C.c_int, [_h, C.c_uint, C.c_double, C.c_int]),
     "pgf_batch_ctl_read": (C.c_int, [_h, _dp, C.POINTER(C.c_uint8), _dp, C.c_int]),
+    "pgf_kkt_apply": (C.c_int, [_h, _dp, _dp]),
     "pgf_set_refinement": (C.c_int, [_h, C.c_int, C.c_double, C.c_double]),
     "pgf_refinement_stats": (C.c_int, [_h, _ip, _ip, _dp]),
     "pgf_debug_fail_next_chain": (C.c_int, [_h]),

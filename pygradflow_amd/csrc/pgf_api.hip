@@ -838,6 +838,28 @@ int pgf_linear_solve(pgf_handle h, const double *rhs, int trans, double *sol) {
   return PGF_OK;
 }
 
+// out <- K v for the reduced KKT matrix of the current mask, applied from H, J and the mask on
+// the device (no N x N copy crosses PCIe): the products of the condition estimate
+int pgf_kkt_apply(pgf_handle h, const double *v, double *out) {
+  if (!h) return PGF_INVALID;
+  int rc;
+  if ((rc = check_ready(h))) return rc;
+  if (h->sparse) return fail(h, PGF_NOT_READY, "pgf_kkt_apply: dense mode only");
+  if (h->N && (!v || !out)) return fail(h, PGF_INVALID, "null argument");
+  if (h->N == 0) return PGF_OK;
+  (void)hipSetDevice(h->device);
+  // r = 0 - K v with the residual kernels: rs_d holds v, rs_r starts as the zero right-hand side
+  if ((rc = up(h, h->rs_d, v, (size_t)h->N * sizeof(double)))) return rc;
+  HIPCHK(h, hipMemsetAsync(h->rs_r, 0, (size_t)(h->N + 1) * sizeof(double), h->stream));
+  launch_kkt_residual(h->stream, h->n, h->m, h->nI, h->lamb, h->delta, h->H, h->ldh, h->J, h->ldj,
+                      h->idxI, h->pos, h->mask, h->rs_r, h->rs_d, h->rs_v, h->rs_lv, h->rs_u,
+                      h->rs_wy, h->partial, PGF_GEMVT_PARTS, h->rs_r, h->rs_red);
+  if ((rc = down(h, out, h->rs_r, (size_t)h->N * sizeof(double)))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < h->N; ++i) out[i] = -out[i];
+  return PGF_OK;
+}
+
 int pgf_get_kkt(pgf_handle h, double *K_out, int64_t ldk_out) {
   if (!h) return PGF_INVALID;
   int rc;

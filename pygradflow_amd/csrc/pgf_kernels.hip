@@ -734,11 +734,10 @@ __global__ void k_expand_sol(int n, int nI, const int *__restrict__ pos, const u
 // red[0..2] <- max |r|, max |rhs|, max |s| (bit patterns of non-negative doubles order like
 // integers; red zeroed by the caller)
 __global__ __launch_bounds__(256) void k_kkt_residual(int N, int nI, const int *__restrict__ idxI,
-                                                      const double *__restrict__ rhs,
+                                                      const double *rhs,  // may alias r
                                                       const double *__restrict__ sol,
                                                       const double *__restrict__ u,
-                                                      const double *__restrict__ wy,
-                                                      double *__restrict__ r,
+                                                      const double *__restrict__ wy, double *r,
                                                       unsigned long long *__restrict__ red) {
   __shared__ double sh[3][256];
   const int i = blockIdx.x * 256 + threadIdx.x;

@@ -487,13 +487,32 @@ class HipStepSolver:
         if getattr(params, "report_rcond", False):
             from .cond_estimate import estimate_rcond
 
-            if self.sparse:
-                Kfull = self._host_reduced_kkt()
-            else:
-                Kl = self.kkt_matrix()
-                Kfull = Kl + np.tril(Kl, -1).T
-            rcond = estimate_rcond(Kfull, self.solver, params)
+            # the estimator's products K x, K' x: on the device for the dense path (no N x N
+            # copy over PCIe), with the host CSR matrix in banded mode
+            Kop = self._host_reduced_kkt() if self.sparse else _DeviceKkt(self)
+            rcond = estimate_rcond(Kop, self.solver, params)
         return StepResult(iterate, dx, dy, self.active_set, rcond, xn=xn, yn=yn, diff=diff.value)
+
+
+class _DeviceKkt:
+    """``mat`` of the condition estimate: ``mat @ x`` and ``mat.T @ x`` through
+    ``pgf_kkt_apply`` (K is symmetric)."""
+
+    def __init__(self, owner: HipStepSolver):
+        self._o = owner
+        n_red = owner.reduced_dims()[1]
+        self.shape = (n_red, n_red)
+
+    @property
+    def T(self):
+        return self
+
+    def __matmul__(self, x):
+        o = self._o
+        x = _lib.as_f64(x)
+        out = np.empty_like(x)
+        _lib.check(o._lib.pgf_kkt_apply(o._hd.h, _lib.dptr(x), _lib.dptr(out)), o._hd.h, "pgf_kkt_apply")
+        return out
 
 
 class _DeviceFactorView:
