@@ -761,24 +761,23 @@ __global__ __launch_bounds__(1024) void k_chain_update(double *K, int64_t ldk, i
     chain_body<16>(smem, K, ldk, c0, nb, dvec, dinv, flags, Linv, LinvT, dbg);
     return;
   }
-  const int sub = threadIdx.x >> 8, ltid = threadIdx.x & 255;
   // linear tile id -> (tile row by, tile column bx): row by holds the tiles not entirely
-  // above the diagonal
-  int t = ((int)blockIdx.x - 1) * 4 + sub;
-  const int tr = (nrows - row0 + 63) / 64, tc = (colEnd - col0 + 63) / 64;
+  // above the diagonal.  ONE 128 x 128 tile per workgroup, 16 wavefronts as 4 x 4 with 2 x 2
+  // MFMA tiles each and two LDS stages: the chain's LDS footprint allows one workgroup per CU,
+  // so the 16 wavefronts share one staged panel pair instead of staging four 64 x 64 tiles'
+  // panels separately (227 -> ? us on the first block, where the update decides the launch).
+  int t = (int)blockIdx.x - 1;
+  const int tr = (nrows - row0 + 127) / 128, tc = (colEnd - col0 + 127) / 128;
   int by = 0;
   while (by < tr) {
-    const int nc = min(tc, (row0 + 64 * by + 63 - col0) / 64 + 1);
+    const int nc = min(tc, (row0 + 128 * by + 127 - col0) / 128 + 1);
     if (t < nc) break;
     t -= nc;
     ++by;
   }
-  // a group past the last tile still takes part in the workgroup's barriers: it runs an
-  // all-masked tile (i0 = nrows: nothing is loaded or stored)
-  const int i0 = by < tr ? row0 + 64 * by : nrows;
-  const int j0 = by < tr ? col0 + 64 * t : col0;
-  update_tile<64, 64, 16>(smem + sub * ((64 + 64) * 18 * 8), ltid, i0, j0, K, ldk, W, ldw, N, nrows,
-                          colEnd, kc0, KB);
+  if (by >= tr) return;
+  update_tile<128, 128, 16, 4, 4, 1>(smem, threadIdx.x, row0 + 128 * by, col0 + 128 * t, K, ldk, W,
+                                     ldw, N, nrows, colEnd, kc0, KB);
 }
 
 // ------------------------------------------------------------------ host schedule
@@ -881,11 +880,11 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
     const int row0 = c1 + nb1;
     int ntiles = 0;
     if (row0 < nrows) {
-      const int tr = (nrows - row0 + 63) / 64, tc = (N - c1 + 63) / 64;
-      for (int by = 0; by < tr; ++by) ntiles += std::min(tc, (row0 + 64 * by + 63 - c1) / 64 + 1);
+      const int tr = (nrows - row0 + 127) / 128, tc = (N - c1 + 127) / 128;
+      for (int by = 0; by < tr; ++by) ntiles += std::min(tc, (row0 + 128 * by + 127 - c1) / 128 + 1);
     }
     if (fused() && !p && ntiles > 0) {
-      hipLaunchKernelGGL(k_chain_update, dim3(1 + (ntiles + 3) / 4), dim3(1024), 0, s, f.K, f.ldk, c1,
+      hipLaunchKernelGGL(k_chain_update, dim3(1 + ntiles), dim3(1024), 0, s, f.K, f.ldk, c1,
                          nb1, f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, (long long *)nullptr, Wb, ldw,
                          N, nrows, row0, c1, N, c0, OB);
     } else {
