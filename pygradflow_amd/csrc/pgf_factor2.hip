@@ -792,6 +792,11 @@ static int chain_waves() {
   return nw;
 }
 
+static int trsm_rows() {
+  static const int r = (getenv("PGF_TRSM_ROWS") && atoi(getenv("PGF_TRSM_ROWS")) == 32) ? 32 : 16;
+  return r;
+}
+
 static bool fused() {
   static const bool on = !(getenv("PGF_FUSED") && atoi(getenv("PGF_FUSED")) == 0);
   return on;
@@ -857,8 +862,12 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
     const int below = nrows - (c0 + nb);
     if (below > 0) {
       span_begin(pr.trsm_spans);
-      hipLaunchKernelGGL(k_trsm_block<16>, dim3((below + 15) / 16), dim3(256), 0, s, f.K, f.ldk, Wb,
-                         ldw, nrows, c0, nb, f.dinv, f.Linv);
+      if (trsm_rows() == 32)
+        hipLaunchKernelGGL(k_trsm_block<32>, dim3((below + 31) / 32), dim3(512), 0, s, f.K, f.ldk, Wb,
+                           ldw, nrows, c0, nb, f.dinv, f.Linv);
+      else
+        hipLaunchKernelGGL(k_trsm_block<16>, dim3((below + 15) / 16), dim3(256), 0, s, f.K, f.ldk, Wb,
+                           ldw, nrows, c0, nb, f.dinv, f.Linv);
       span_end(pr.trsm_spans);
     }
   };
