@@ -388,8 +388,14 @@ def main():
             # extract + log2(N/8) invert/reduce levels + the back-substitution levels); the
             # "flops" slot of the profile carries its algorithmic bytes
             gbs = pr["update_flops"] / (pr["update_ms"] * 1e-3) / 1e9
+            # algorithmic bytes of one STEP (K as CSR read + factors written +
+            # read twice + ~12 vector passes): 43 MB for config 3, ~3 MB for config 5
+            step_bytes = 3.0e6 if wl.get("box") else 43.0e6
+            step_gbs = step_bytes * (args.steps / elapsed) / 1e9
             roof = dict(bound="hbm", kernel="bcr_solve (k_bcr_extract/invert/reduce/back)",
                         achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS,
+                        step_bytes=step_bytes, step_achieved=step_gbs,
+                        step_frac=step_gbs / PEAK_HBM_GBS,
                         traffic=None, spans_per_step=pr["update_launches"] / args.steps,
                         avg_span_us=1e3 * pr["update_ms"] / pr["update_launches"],
                         bytes_per_span=pr["update_flops"] / pr["update_launches"],
@@ -417,8 +423,10 @@ def main():
             )
             # the STEP against the FP64-MFMA roof -- algorithmic flops of one
             # Full Newton step (factor N^3/3, solves 2 N^2, residual 2 n^2 + 4 n m) x steps/s
-            N_ = n + m
+            # reduced size: inactive variables + constraints (= n + m without active bounds)
+            N_ = n - int(np.count_nonzero(dn.mask())) + m
             step_flops = N_ ** 3 / 3.0 + 2.0 * N_ ** 2 + 2.0 * n * n + 4.0 * n * m
+            roof["reduced_size"] = N_
             roof["step_flops"] = step_flops
             roof["step_achieved"] = step_flops * (args.steps / elapsed) / 1e12
             roof["step_frac"] = roof["step_achieved"] / PEAK_FP64_MFMA_TFLOPS

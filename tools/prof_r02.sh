@@ -9,9 +9,10 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pf1 -- python bench.py --st
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pm1 -- python bench.py --steps 3 --warmup 0 --no-cpu-baseline > /dev/null 2>&1 && python tools/pmc_mfma_summary.py $O/pm1 > $O/pmc_mfma.txt 2>&1 && echo mfma done
 python bench.py --workload batch256_n1024_m256 --steps 6 --warmup 2 > $O/bench_batch256.json 2> $O/bench_batch.err && echo benchb done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ksb -- python bench.py --workload batch256_n1024_m256 --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 && cp $(ls $O/ksb/*/*kernel_stats.csv | head -1) $O/batch256_kernel_stats.csv && echo ksb done
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pfb -- python bench.py --workload batch256_n1024_m256 --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1 && rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pwb -- python bench.py --workload batch256_n1024_m256 --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1 && python tools/pmc_summary.py $O/pfb $O/pwb $O/pmc_batch.json > $O/batch256_pmc_traffic.txt 2>&1 && echo pmcb done
 python bench.py --workload sparse_ocp_n100000_m50000 --steps 100 --warmup 5 > $O/bench_sparse_ocp.json 2>/dev/null && echo ocp done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kso -- python bench.py --workload sparse_ocp_n100000_m50000 --steps 20 --warmup 2 --no-cpu-baseline > /dev/null 2>&1 && cp $(ls $O/kso/*/*kernel_stats.csv | head -1) $O/sparse_ocp_kernel_stats.csv && echo kso done
 python bench.py --workload box_qp_n16384 --steps 100 --warmup 5 > $O/bench_box_qp.json 2>/dev/null && echo box done
 python bench.py --workload box_qp_dense_n16384 --steps 6 --warmup 2 > $O/bench_box_qp_dense.json 2>/dev/null && echo boxd done
-rm -rf $O/ks $O/pf1 $O/pw1 $O/pm1 $O/ksb $O/kso
+rm -rf $O/ks $O/pf1 $O/pw1 $O/pm1 $O/ksb $O/kso $O/pfb $O/pwb
 ls -la $O
