@@ -62,6 +62,10 @@ struct pgf_solver {
   double refine_tol = 1e-11, refine_fail = 1e-7;
   int stat_refined = 0, stat_lu = 0;
   double stat_last_rel = 0.0;
+  // the factorisation step's own residual was far below the tolerance: the back-solve steps
+  // with the same factor (same backward error, other right-hand sides) skip the check
+  bool factor_clean = false;
+  bool rs_skipped = false;
 };
 
 struct pgf_linsolver {
@@ -245,6 +249,7 @@ static int down(pgf_handle h, void *dst, const void *src, size_t bytes) {
 static void invalidate_factor(pgf_handle h) {
   h->fac.factored = false;
   h->lu_active = false;
+  h->factor_clean = false;
 }
 
 int pgf_set_bounds(pgf_handle h, const double *lb, const double *ub) {
@@ -512,8 +517,10 @@ static void enqueue_step_update(pgf_handle h) {
 
 // r = rhs - K s of the solve just enqueued, with K applied from H, J and the mask (the factor
 // overwrote the assembled matrix); the three maxima reach the host with the next sync
-static void enqueue_residual(pgf_handle h) {
+static void enqueue_residual(pgf_handle h, bool may_skip = false) {
   if (h->sparse || !h->refine_mode) return;
+  h->rs_skipped = may_skip && h->factor_clean;
+  if (h->rs_skipped) return;
   launch_kkt_residual(h->stream, h->n, h->m, h->nI, h->lamb, h->delta, h->H, h->ldh, h->J, h->ldj,
                       h->idxI, h->pos, h->mask, h->rhs, h->sol, h->rs_v, h->rs_lv, h->rs_u, h->rs_wy,
                       h->partial, PGF_GEMVT_PARTS, h->rs_r, h->rs_red);
@@ -537,9 +544,10 @@ static double residual_rel(pgf_handle h) {
 // fails too does the call report PGF_SINGULAR -> LinearSolverError -> the step controller's
 // reject-and-halve path.
 static int refine_if_needed(pgf_handle h, bool swapped, bool with_step = true) {
-  if (h->sparse || !h->refine_mode || h->N == 0) return PGF_OK;
+  if (h->sparse || !h->refine_mode || h->N == 0 || h->rs_skipped) return PGF_OK;
   double rel = residual_rel(h);
   h->stat_last_rel = rel;
+  if (h->last_solve == 1) h->factor_clean = rel <= 1e-3 * h->refine_tol;
   if (rel <= h->refine_tol) return PGF_OK;
   hipStream_t s = h->stream;
   auto unswap = [&]() {
@@ -709,7 +717,7 @@ static int newton_core_async(pgf_handle h, bool *did_factor) {
     else
       HIPCHK(h, ldlt_solve_async(h->fac, h->rhs, h->sol));
   }
-  enqueue_residual(h);
+  enqueue_residual(h, !*did_factor);
   enqueue_step_update(h);
   return PGF_OK;
 }

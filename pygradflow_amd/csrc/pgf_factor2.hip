@@ -761,12 +761,12 @@ __global__ __launch_bounds__(1024) void k_chain_update(double *K, int64_t ldk, i
     chain_body<16>(smem, K, ldk, c0, nb, dvec, dinv, flags, Linv, LinvT, dbg);
     return;
   }
+  int t = (int)blockIdx.x - 1;
   // linear tile id -> (tile row by, tile column bx): row by holds the tiles not entirely
   // above the diagonal.  ONE 128 x 128 tile per workgroup, 16 wavefronts as 4 x 4 with 2 x 2
   // MFMA tiles each and two LDS stages: the chain's LDS footprint allows one workgroup per CU,
   // so the 16 wavefronts share one staged panel pair instead of staging four 64 x 64 tiles'
   // panels separately (227 -> ? us on the first block, where the update decides the launch).
-  int t = (int)blockIdx.x - 1;
   const int tr = (nrows - row0 + 127) / 128, tc = (colEnd - col0 + 127) / 128;
   int by = 0;
   while (by < tr) {
