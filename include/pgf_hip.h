@@ -315,6 +315,14 @@ int pgf_refinement_stats(pgf_handle h, int *refined, int *lu_fallbacks, double *
  * can be tested; pgf_debug_chain_enable(1) switches the chained kernels back on. */
 int pgf_debug_fail_next_chain(pgf_handle h);
 int pgf_debug_chain_enable(int on);
+/* The dense factorisation's diagonal chain hands work to two helper workgroups of the same
+ * launch; a failed placement check or a timed-out hand-over switches them off
+ * for the rest of the process and the factorisation (and the step built on it) is repeated
+ * inside the call that notices.  pgf_debug_fail_next_helper makes the next factorisation of
+ * this handle report such a failure; pgf_debug_chain_helpers(1 / 0) switches the helpers on /
+ * off, (-1) only queries; returns the previous state (1 = on). */
+int pgf_debug_fail_next_helper(pgf_handle h);
+int pgf_debug_chain_helpers(int on);
 
 #ifdef __cplusplus
 }

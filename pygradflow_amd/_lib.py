@@ -99,6 +99,8 @@ SIGNATURES = {
     "pgf_refinement_stats": (C.c_int, [_h, _ip, _ip, _dp]),
     "pgf_debug_fail_next_chain": (C.c_int, [_h]),
     "pgf_debug_chain_enable": (C.c_int, [C.c_int]),
+    "pgf_debug_fail_next_helper": (C.c_int, [_h]),
+    "pgf_debug_chain_helpers": (C.c_int, [C.c_int]),
 }
 
 _lib = None

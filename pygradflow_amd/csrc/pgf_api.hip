@@ -501,12 +501,29 @@ static int factor_async(pgf_handle h, bool with_rhs) {
   return PGF_OK;
 }
 
+// internal: the factorisation just awaited must be repeated (its chain helpers failed their
+// hand-over checks and are switched off now, ldlt_finish); never leaves the library
+#define PGF_RETRY_FACTOR (-2)
+static const char *k_helper_msg =
+    "the dense factorisation failed its hand-over checks with and without helper workgroups";
+
 static int factor_finish(pgf_handle h) {
   hipError_t e;
   const int st = ldlt_finish(h->fac, &e);
   if (st < 0) return hip_fail(h, e, "factor");
+  if (st == 2) return PGF_RETRY_FACTOR;
   if (st == 1) return fail(h, PGF_SINGULAR, "zero or non-finite pivot in LDL^T of the KKT matrix");
   return PGF_OK;
+}
+
+// assemble + factorise (no right-hand side row) and wait
+static int factor_sync(pgf_handle h) {
+  int rc;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if ((rc = factor_async(h, false))) return rc;
+    if ((rc = factor_finish(h)) != PGF_RETRY_FACTOR) return rc;
+  }
+  return fail(h, PGF_HIP_ERROR, k_helper_msg);
 }
 
 static void enqueue_step_update(pgf_handle h) {
@@ -640,8 +657,7 @@ int pgf_factor(pgf_handle h, int *n_neg) {
   int rc;
   if ((rc = check_ready(h))) return rc;
   (void)hipSetDevice(h->device);
-  if ((rc = factor_async(h, false))) return rc;
-  if ((rc = factor_finish(h))) return rc;
+  if ((rc = factor_sync(h))) return rc;
   if (n_neg) *n_neg = h->fac.n_neg;
   return PGF_OK;
 }
@@ -736,12 +752,20 @@ int pgf_newton_solve(pgf_handle h, const double *x, const double *y, const doubl
   if ((rc = up(h, h->c, c, h->m * sizeof(double)))) return rc;
   h->eval_fresh = false;
   bool did_factor;
-  if ((rc = newton_core_async(h, &did_factor))) return rc;
-  if ((rc = down(h, h->h_scal, h->scal, sizeof(double)))) return rc;
-  if (did_factor) {
-    if ((rc = factor_finish(h))) return rc;
-  } else {
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (int attempt = 0;; ++attempt) {
+    if ((rc = newton_core_async(h, &did_factor))) return rc;
+    if ((rc = down(h, h->h_scal, h->scal, sizeof(double)))) return rc;
+    if (did_factor) {
+      rc = factor_finish(h);
+      if (rc == PGF_RETRY_FACTOR) {  // once more, without the chain's helper workgroups
+        if (attempt == 0) continue;
+        return fail(h, PGF_HIP_ERROR, k_helper_msg);
+      }
+      if (rc) return rc;
+    } else {
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    break;
   }
   if ((rc = chain_recover(h, false))) return rc;
   if ((rc = refine_if_needed(h, false))) return rc;
@@ -821,8 +845,7 @@ int pgf_linear_solve(pgf_handle h, const double *rhs, int trans, double *sol) {
   if (h->N && (!rhs || !sol)) return fail(h, PGF_INVALID, "null argument");
   (void)hipSetDevice(h->device);
   if (!h->fac.factored) {
-    if ((rc = factor_async(h, false))) return rc;
-    if ((rc = factor_finish(h))) return rc;
+    if ((rc = factor_sync(h))) return rc;
   }
   if ((rc = up(h, h->rhs, rhs, h->N * sizeof(double)))) return rc;
   if (h->lu_active) {  // the pivoted factor took over for this matrix (refine_if_needed)
@@ -1151,10 +1174,23 @@ int pgf_qp_sync(pgf_handle h, int *n_neg, double *diff) {
   h->step_pending = false;
   (void)hipSetDevice(h->device);
   hipError_t e;
-  const int st = ldlt_finish(h->fac, &e);  // flags are only rewritten by a factor launch
+  int st = ldlt_finish(h->fac, &e);  // flags are only rewritten by a factor launch
+  int rc;
+  if (st == 2) {
+    // the chain's helper workgroups failed their checks (off now): the step is computed again
+    // from the point it started at
+    std::swap(h->x, h->xn);
+    std::swap(h->y, h->yn);
+    bool did_factor;
+    if ((rc = newton_core_async(h, &did_factor))) return rc;
+    std::swap(h->x, h->xn);
+    std::swap(h->y, h->yn);
+    if ((rc = down(h, h->h_scal, h->scal, sizeof(double)))) return rc;
+    st = ldlt_finish(h->fac, &e);
+    if (st == 2) return fail(h, PGF_HIP_ERROR, k_helper_msg);
+  }
   if (st < 0) return hip_fail(h, e, "step");
   if (st == 1) return fail(h, PGF_SINGULAR, "zero or non-finite pivot in LDL^T of the KKT matrix");
-  int rc;
   if ((rc = chain_recover(h, true))) return rc;
   if ((rc = refine_if_needed(h, true))) return rc;
   if (n_neg) *n_neg = h->fac.n_neg;
@@ -1187,6 +1223,18 @@ int pgf_debug_fail_next_chain(pgf_handle h) {
 int pgf_debug_chain_enable(int on) {
   ldlt_chain_set_enabled(on != 0);
   return PGF_OK;
+}
+
+int pgf_debug_fail_next_helper(pgf_handle h) {
+  if (!h) return PGF_INVALID;
+  h->fac.inject_helper_failure = 1;
+  return PGF_OK;
+}
+
+int pgf_debug_chain_helpers(int on) {
+  const int was = ldlt_chain_helpers_enabled() ? 1 : 0;
+  if (on == 0 || on == 1) ldlt_chain_helpers_set(on == 1);
+  return was;
 }
 
 int pgf_qp_step(pgf_handle h, unsigned policy, double tau, int inertia_check, int *n_neg,
@@ -1890,7 +1938,18 @@ int pgf_ls_create_dense(int N, const double *A, int64_t lda, int symmetric, int 
       if (e != hipSuccess) break;
     }
     if ((e = ldlt_factor_async(ls->fac, N, N)) != hipSuccess) break;
-    const int st = ldlt_finish(ls->fac, &e);
+    int st = ldlt_finish(ls->fac, &e);
+    if (st == 2) {  // chain helpers failed their checks (off now): upload and factorise again
+      if (N) {
+        e = hipMemcpy2DAsync(ls->fac.K, (size_t)ls->fac.ldk * sizeof(double), A,
+                             (size_t)lda * sizeof(double), (size_t)N * sizeof(double), N,
+                             hipMemcpyHostToDevice, ls->stream);
+        if (e != hipSuccess) break;
+      }
+      if ((e = ldlt_factor_async(ls->fac, N, N)) != hipSuccess) break;
+      st = ldlt_finish(ls->fac, &e);
+      if (st == 2) rc = PGF_HIP_ERROR;
+    }
     if (st < 0) break;
     if (st == 1) rc = PGF_SINGULAR;
   } while (0);

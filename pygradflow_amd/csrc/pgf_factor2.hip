@@ -422,12 +422,222 @@ __device__ __forceinline__ void inv_block_column(const double (*Lg)[C_LD], doubl
   }
 }
 
+// ---- helper workgroups of the chain (same launch, same XCD: workgroup ids 0, 8 and 16)
+// The chain workgroup hands each finished 64-column sub-panel to two helpers through stamps in
+// global memory: helper T applies the sub-panel to the part of the diagonal block the chain
+// does not need for its NEXT sub-panel, helper I inverts the sub-panel's unit-lower tile.  Both
+// used to sit at the end of the chain's own critical path.  Protocol as for the chained solves
+// (pgf_ldlt.hip): producer drains its stores (s_waitcnt vmcnt(0)) behind a barrier, then ONE
+// lane stores the epoch stamp with an L1-bypassing access; the consumer polls it (bounded) and
+// reads the data through its own, freshly invalidated L1 or with L1-bypassing loads; producer
+// and consumer share an L2 because ids that are multiples of 8 land on one XCD -- checked at run
+// time through HW_REG_XCC_ID.  A failed check or a timed-out wait sets flags[2]; the host then
+// repeats the factorisation without helpers.
+#define HC_STAMP 0  // [0, 4): sub-panel s written back (chain -> helpers)
+#define HC_DONE 4   // [4, 8): deferred tiles of sub-panel s updated (helper T -> chain)
+#define HC_XCC 8    // max over the three roles of (epoch << 4 | xcc)
+#define HC_WORDS 16
+#define HELP_SPIN_LIMIT (1 << 18)
+
+__device__ __forceinline__ void help_wait(const int *stamp, int epoch, int *flags) {
+  for (int it = 0; it < HELP_SPIN_LIMIT; ++it) {
+    if (__hip_atomic_load(stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  atomicOr(&flags[2], 2);
+}
+__device__ __forceinline__ void help_post(int *stamp, int epoch) {
+  __hip_atomic_store(stamp, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void help_check_xcc(int *hc, int epoch, int *flags) {
+  const int ep = epoch & 0x7ffffff;
+  const int mine = (ep << 4) | (int)(__builtin_amdgcn_s_getreg(6164) & 15);  // XCC_ID[3:0]
+  const int old = atomicMax(&hc[HC_XCC], mine);
+  if ((old >> 4) == ep && old != mine) atomicOr(&flags[2], 1);
+}
+__device__ __forceinline__ double ld_agent(const double *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// inverse of the unit-lower 64 x 64 diagonal tile g of the block (rows / columns from b0), by
+// the four wavefronts [4 slot, 4 slot + 4) of the workgroup; every thread of the workgroup
+// calls this (barriers), `live` says whether its wavefront group has a tile.  Blocked by 16:
+// wavefront v inverts the 16 x 16 diagonal sub-tile v by substitution (lane c <-> column c),
+// then wavefront q < 3 builds block column q of the inverse top down,
+//   X_pq = -D_p sum_{r = q}^{p-1} L_pr X_rq   (D_p = inv(L_pp), X_qq = D_q),
+// with MFMA: a 16 x 16 accumulator (row (l >> 4) + 4 reg, column l & 15) IS the B operand
+// of the next four k-steps, so the X_rq stay in registers.  Stored as inv and as its
+// transpose, [tile][row][64]: forward and backward solves both read coalesced rows.
+__device__ __forceinline__ void invert_tile(unsigned char *smem, const double *K, int64_t ldk,
+                                            int b0, int nbw, bool live, double *__restrict__ Linv,
+                                            double *__restrict__ LinvT) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4, v = wave & 3;
+  double(*Lg)[C_LD] = reinterpret_cast<double(*)[C_LD]>(smem + (size_t)(wave >> 2) * 64 * C_LD * 8);
+  if (live) {
+    for (int idx = tid & 255; idx < 64 * 32; idx += 256) {
+      const int row = idx >> 5, c2 = (idx & 31) * 2;
+      double2_t t = (double2_t){0.0, 0.0};
+      if (row < nbw) {
+        const double *src = K + (int64_t)(b0 + row) * ldk + b0 + c2;
+        if (c2 + 1 < row) t = *reinterpret_cast<const double2_t *>(src);
+        else if (c2 < row) t.x = *src;
+      }
+      if (c2 == row) t.x = 1.0;
+      if (c2 + 1 == row) t.y = 1.0;
+      *reinterpret_cast<double2_t *>(&Lg[row][c2]) = t;
+    }
+  }
+  __syncthreads();
+  if (live && lane < 16) {
+    double y[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) y[j] = (j == lane) ? 1.0 : 0.0;
+#pragma unroll
+    for (int t = 0; t < 15; ++t) {
+      const double yt = y[t];
+#pragma unroll
+      for (int j = t + 1; j < 16; ++j) y[j] = fma(-yt, Lg[16 * v + j][16 * v + t], y[j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) Lg[16 * v + j][16 * v + lane] = y[j];
+  }
+  __syncthreads();
+  double4_t Xo[3];
+  if (live) {
+    if (v == 0) inv_block_column<0>(Lg, Xo, l15, l4);
+    else if (v == 1) inv_block_column<1>(Lg, Xo, l15, l4);
+    else if (v == 2) inv_block_column<2>(Lg, Xo, l15, l4);
+  }
+  __syncthreads();  // every wavefront is done reading the L blocks: the X blocks go in place
+  if (live && v < 3) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int pb = v + 1 + t;
+      if (pb < 4) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) Lg[16 * pb + l4 + 4 * rr][16 * v + l15] = Xo[t][rr];
+      }
+    }
+  }
+  __syncthreads();
+  if (live) {
+    double *o = Linv + (size_t)(b0 / 64) * 4096;
+    double *ot = LinvT + (size_t)(b0 / 64) * 4096;
+    for (int idx = tid & 255; idx < 64 * 64; idx += 256) {
+      const int row = idx >> 6, col = idx & 63;
+      o[idx] = Lg[row][col];
+      ot[idx] = Lg[col][row];
+    }
+  }
+  __syncthreads();  // Lg is refilled by the next pass
+}
+
+// 16 x 16 sub-tiles on or below the diagonal of a lower-triangular region of nt 64-row tiles,
+// tile (I, J), J <= I, holding 10 (I == J) or 16 of them; (mi, mj) = offsets inside the region
+__device__ __forceinline__ void decode_subtile(int e, int &mi, int &mj) {
+  int I = 0, J = 0;
+  while (true) {
+    const int cnt = (I == J) ? 10 : 16;
+    if (e < cnt) break;
+    e -= cnt;
+    if (++J > I) {
+      J = 0;
+      ++I;
+    }
+  }
+  int ti, tj;
+  if (I == J) {
+    ti = (e >= 6) ? 3 : (e >= 3) ? 2 : (e >= 1) ? 1 : 0;
+    tj = e - ti * (ti + 1) / 2;
+  } else {
+    ti = e >> 2;
+    tj = e & 3;
+  }
+  mi = 64 * I + 16 * ti;
+  mj = 64 * J + 16 * tj;
+}
+
+// helper T (workgroup 8): for every sub-panel s with rows beyond the NEXT sub-panel, apply it to
+// the lower triangle of those rows / columns [cb + 128, bend): C -= (L D) L^T with L read back
+// from global memory (the chain wrote L = X D^-1; X itself stays in its LDS)
 template <int NW>
+__device__ __forceinline__ void helper_tiles(unsigned char *smem, double *K, int64_t ldk, int c0,
+                                             int nb, const double *dvec, int *hc, int epoch,
+                                             int *flags) {
+  constexpr int NT = 64 * NW;
+  double(*Mh)[C_LD] = reinterpret_cast<double(*)[C_LD]>(smem);
+  double *dDs = reinterpret_cast<double *>(smem + 128 * C_LD * 8);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int bend = c0 + nb, ns = (nb + 63) / 64;
+  if (tid == 0) help_check_xcc(hc, epoch, flags);
+  for (int s = 0; s + 2 < ns; ++s) {
+    const int cb = c0 + 64 * s, r0 = cb + 128;
+    const int rows = bend - r0, rowsp = (rows + 63) & ~63, nt = rowsp / 64;
+    if (tid == 0) help_wait(hc + HC_STAMP + s, epoch, flags);
+    __syncthreads();
+    for (int p = tid; p < rowsp * 32; p += NT) {
+      const int row = p >> 5, c2 = (p & 31) * 2;
+      double2_t t = (double2_t){0.0, 0.0};
+      if (row < rows) t = *reinterpret_cast<const double2_t *>(K + (int64_t)(r0 + row) * ldk + cb + c2);
+      *reinterpret_cast<double2_t *>(&Mh[row][c2]) = t;
+    }
+    if (tid < 64) dDs[tid] = dvec[cb + tid];
+    __syncthreads();
+    const int total = nt * (nt + 1) / 2 * 16 - nt * 6;
+    for (int e = wave; e < total; e += NW) {
+      int mi, mj;
+      decode_subtile(e, mi, mj);
+      const int gi = r0 + mi, gj = r0 + mj, j = gj + l15;
+      double4_t c = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = gi + l4 + 4 * r;
+        if (i < bend && j < bend && j <= i) c[r] = ld_agent(K + (int64_t)i * ldk + j);
+      }
+#pragma unroll 4
+      for (int ks = 0; ks < 64; ks += 4) {
+        const double av = -Mh[mi + l15][ks + l4] * dDs[ks + l4];
+        const double bv = Mh[mj + l15][ks + l4];
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = gi + l4 + 4 * r;
+        if (i < bend && j < bend && j <= i) K[(int64_t)i * ldk + j] = c[r];
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) help_post(hc + HC_DONE + s, epoch);
+  }
+}
+
+// helper I (workgroup 16): the inverse of every sub-panel's diagonal tile as soon as it is final
+template <int NW>
+__device__ __forceinline__ void helper_inverses(unsigned char *smem, const double *K, int64_t ldk,
+                                                int c0, int nb, int *hc, int epoch, int *flags,
+                                                double *__restrict__ Linv,
+                                                double *__restrict__ LinvT) {
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int bend = c0 + nb, ns = (nb + 63) / 64;
+  if (tid == 0) help_check_xcc(hc, epoch, flags);
+  for (int s = 0; s < ns; ++s) {
+    const int b0 = c0 + 64 * s;
+    if (tid == 0) help_wait(hc + HC_STAMP + s, epoch, flags);
+    __syncthreads();
+    invert_tile(smem, K, ldk, b0, min(64, bend - b0), wave < 4, Linv, LinvT);
+  }
+}
+
+template <int NW, bool HELP>
 __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64_t ldk, int c0,
                                            int nb, double *__restrict__ dvec,
                                            double *__restrict__ dinv, int *__restrict__ flags,
                                            double *__restrict__ Linv, double *__restrict__ LinvT,
-                                           long long *__restrict__ dbg) {
+                                           long long *__restrict__ dbg, int *hc, int epoch) {
   double(*M)[C_LD] = reinterpret_cast<double(*)[C_LD]>(smem);
   double(*Wt)[C_WLD] = reinterpret_cast<double(*)[C_WLD]>(smem + CH_ROWS * C_LD * 8);
   double *dD = reinterpret_cast<double *>(smem + CH_ROWS * C_LD * 8 + 2 * 64 * C_WLD * 8);
@@ -445,7 +655,9 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
     if (dbg && tid == 0 && dbi < 32) dbg[dbi++] = wall_clock64(); \
   } while (0)
   CH_STAMP();
+  if (HELP && tid == 0) help_check_xcc(hc, epoch, flags);
 
+  bool preloaded = false;
   for (int s = 0; s < ns; ++s) {
     const int cb = c0 + 64 * s;
     const int ncol = min(64, bend - cb);
@@ -453,8 +665,9 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
     const int ownp = (own + 63) & ~63;       // padded to whole wavefronts of rows
     if (tid == 0) s_bad = 0;
     // ---- load the stack: diagonal tile (identity outside the valid lower triangle) + the
-    // block's rows below, all loads of a lane in flight before its first LDS store
-    {
+    // block's rows below, all loads of a lane in flight before its first LDS store.  Not for
+    // a stack the previous sub-panel's in-block update has left in M already (see there).
+    if (!preloaded) {
       constexpr int NQ = 8192 / NT;
       double2_t v[NQ];
       const int np = (64 + ownp) * 32;
@@ -544,6 +757,9 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
     }
     if (s == 0) CH_STAMP();  // four steps done
     if (wave >= 1 && wave <= 3 && 64 * (wave - 1) < own) chain_b_own(M, 64 * wave + lane, 3, lane);
+    // helper T has had the whole sub-panel to finish what it was handed one sub-panel ago:
+    // everything this sub-panel's in-block update fetches below
+    if (HELP && tid == 0 && s >= 1 && s + 1 < ns) help_wait(hc + HC_DONE + s - 1, epoch, flags);
     __syncthreads();
     CH_STAMP();  // panel factored
 
@@ -553,33 +769,31 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
     // kernel: HBM / Infinity Cache, ~2 us) is paid once and hides behind the write-back.
     // Only 16 x 16 sub-tiles on or below the diagonal are enumerated, dealt round-robin: the
     // phase is bound by the CU's matrix pipes, every wavefront should carry the same number.
-    constexpr int MT = (78 + NW - 1) / NW;  // sub-tiles per wavefront, at most (78 = 3*10 + 3*16)
+    // With helpers only the tiles of the NEXT sub-panel's columns are this workgroup's: tile
+    // column 0 of the region, 10 + 16 (nt - 1) sub-tiles; the rest is helper T's.
+    constexpr int MT = ((HELP ? 42 : 78) + NW - 1) / NW;  // sub-tiles per wavefront, at most
     const int nt = ownp / 64;
-    const int total = nt * (nt + 1) / 2 * 16 - nt * 6;
+    const int total = HELP ? (nt ? 10 + 16 * (nt - 1) : 0) : nt * (nt + 1) / 2 * 16 - nt * 6;
     auto decode = [&](int e, int &gi, int &gj, int &mi, int &mj) {
-      int I = 0, J = 0;
-      while (true) {  // tile (I, J), J <= I, holds 10 (I == J) or 16 live sub-tiles
-        const int cnt = (I == J) ? 10 : 16;
-        if (e < cnt) break;
-        e -= cnt;
-        if (++J > I) {
-          J = 0;
-          ++I;
+      if (HELP) {
+        if (e < 10) {
+          const int ti = (e >= 6) ? 3 : (e >= 3) ? 2 : (e >= 1) ? 1 : 0;
+          mi = 16 * ti;
+          mj = 16 * (e - ti * (ti + 1) / 2);
+        } else {
+          mi = 64 + 16 * ((e - 10) >> 2);  // tile row 1 + (e - 10) / 16, sub-row ((e - 10) / 4) % 4
+          mj = 16 * ((e - 10) & 3);
         }
-      }
-      int ti, tj;
-      if (I == J) {
-        ti = (e >= 6) ? 3 : (e >= 3) ? 2 : (e >= 1) ? 1 : 0;
-        tj = e - ti * (ti + 1) / 2;
       } else {
-        ti = e >> 2;
-        tj = e & 3;
+        decode_subtile(e, mi, mj);
       }
-      mi = 64 + 64 * I + 16 * ti;
-      mj = 64 + 64 * J + 16 * tj;
+      mi += 64;
+      mj += 64;
       gi = cb + mi;
       gj = cb + mj;
     };
+    // whole 64-row tiles below (no ragged edge): the next stack is built in place
+    const bool direct = own > 0 && (own & 63) == 0;
     double4_t ct[MT];
 #pragma unroll
     for (int q = 0; q < MT; ++q) {
@@ -592,7 +806,8 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = gi + l4 + 4 * r;
-          if (i < bend && j < bend && j <= i) ct[q][r] = K[(int64_t)i * ldk + j];
+          if (i < bend && j < bend && j <= i)
+            ct[q][r] = HELP ? ld_agent(K + (int64_t)i * ldk + j) : K[(int64_t)i * ldk + j];
         }
       }
     }
@@ -635,138 +850,124 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
             const double bv = M[mj + l15][ks + l4] * dI[ks + l4];
             c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
           }
-          const int j = gj + l15;
+          if (direct && mj < 128) {
+            ct[q] = c;  // next sub-panel's stack: stays in registers until M is free
+          } else {
+            const int j = gj + l15;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = gi + l4 + 4 * r;
-            if (i < bend && j < bend && j <= i) K[(int64_t)i * ldk + j] = c[r];
+            for (int r = 0; r < 4; ++r) {
+              const int i = gi + l4 + 4 * r;
+              if (i < bend && j < bend && j <= i) K[(int64_t)i * ldk + j] = c[r];
+            }
           }
         }
       }
     }
-    __syncthreads();  // M is reloaded next; the global tiles written above are read back
+    if (HELP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // write-backs have left
+    __syncthreads();  // M is refilled next; the global tiles written above are read back
+    if (HELP && tid == 0) help_post(hc + HC_STAMP + s, epoch);
+    preloaded = direct;
+    if (direct) {
+      // the next sub-panel's stack (columns 64..127 of this one's rows 64..) goes from the
+      // accumulators straight into M: no round trip through global memory
+#pragma unroll
+      for (int q = 0; q < MT; ++q) {
+        const int e = wave + q * NW;
+        if (e < total) {
+          int gi, gj, mi, mj;
+          decode(e, gi, gj, mi, mj);
+          if (mj < 128) {
+            const int cj = mj - 64 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int ri = mi - 64 + l4 + 4 * r;
+              M[ri][cj] = (cj <= ri) ? ct[q][r] : 0.0;
+            }
+          }
+        }
+      }
+      // the six 16 x 16 sub-tiles above the diagonal of the new diagonal tile
+      for (int p = tid; p < 6 * 256; p += NT) {
+        const int t6 = p >> 8, rr = (p >> 4) & 15, cc = p & 15;
+        const int ti = (t6 >= 5) ? 2 : (t6 >= 3) ? 1 : 0;  // (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+        const int tj = (ti == 0) ? 1 + t6 : (ti == 1) ? t6 - 1 : 3;
+        M[16 * ti + rr][16 * tj + cc] = 0.0;
+      }
+    }
     CH_STAMP();  // in-block update done
   }
 
-  // ---- inverses of the block's unit-lower diagonal tiles, four wavefronts per tile, blocked by
-  // 16: wavefront v inverts the 16 x 16 diagonal sub-tile v by substitution (lane c <-> column
-  // c), then wavefront q < 3 builds block column q of the inverse top down,
-  //   X_pq = -D_p sum_{r = q}^{p-1} L_pr X_rq   (D_p = inv(L_pp), X_qq = D_q),
-  // with MFMA: a 16 x 16 accumulator (row (l >> 4) + 4 reg, column l & 15) IS the B operand
-  // of the next four k-steps, so the X_rq stay in registers.  Stored as inv and as its
-  // transpose, [tile][row][64]: forward and backward solves both read coalesced rows.
-  for (int g0 = 0; g0 < ns; g0 += NW / 4) {
-    const int g = g0 + (wave >> 2), v = wave & 3;
-    double(*Lg)[C_LD] = reinterpret_cast<double(*)[C_LD]>(smem + (size_t)(wave >> 2) * 64 * C_LD * 8);
-    const int b0 = c0 + 64 * g;
-    const int nbw = min(64, bend - b0);
-    const bool live = g < ns;
-    if (live) {
-      for (int idx = tid & 255; idx < 64 * 32; idx += 256) {
-        const int row = idx >> 5, c2 = (idx & 31) * 2;
-        double2_t t = (double2_t){0.0, 0.0};
-        if (row < nbw) {
-          const double *src = K + (int64_t)(b0 + row) * ldk + b0 + c2;
-          if (c2 + 1 < row) t = *reinterpret_cast<const double2_t *>(src);
-          else if (c2 < row) t.x = *src;
-        }
-        if (c2 == row) t.x = 1.0;
-        if (c2 + 1 == row) t.y = 1.0;
-        *reinterpret_cast<double2_t *>(&Lg[row][c2]) = t;
-      }
+  // ---- inverses of the block's unit-lower diagonal tiles (invert_tile), four wavefronts per
+  // tile; with helpers this is helper I's work
+  if (!HELP) {
+    for (int g0 = 0; g0 < ns; g0 += NW / 4) {
+      const int g = g0 + (wave >> 2);
+      const int b0 = c0 + 64 * g;
+      invert_tile(smem, K, ldk, b0, min(64, bend - b0), g < ns, Linv, LinvT);
     }
-    __syncthreads();
-    if (live && lane < 16) {
-      double y[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) y[j] = (j == lane) ? 1.0 : 0.0;
-#pragma unroll
-      for (int t = 0; t < 15; ++t) {
-        const double yt = y[t];
-#pragma unroll
-        for (int j = t + 1; j < 16; ++j) y[j] = fma(-yt, Lg[16 * v + j][16 * v + t], y[j]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int j = 0; j < 16; ++j) Lg[16 * v + j][16 * v + lane] = y[j];
-    }
-    __syncthreads();
-    double4_t Xo[3];
-    if (live) {
-      if (v == 0) inv_block_column<0>(Lg, Xo, l15, l4);
-      else if (v == 1) inv_block_column<1>(Lg, Xo, l15, l4);
-      else if (v == 2) inv_block_column<2>(Lg, Xo, l15, l4);
-    }
-    __syncthreads();  // every wavefront is done reading the L blocks: the X blocks go in place
-    if (live && v < 3) {
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const int pb = v + 1 + t;
-        if (pb < 4) {
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) Lg[16 * pb + l4 + 4 * rr][16 * v + l15] = Xo[t][rr];
-        }
-      }
-    }
-    __syncthreads();
-    if (live) {
-      double *o = Linv + (size_t)(b0 / 64) * 4096;
-      double *ot = LinvT + (size_t)(b0 / 64) * 4096;
-      for (int idx = tid & 255; idx < 64 * 64; idx += 256) {
-        const int row = idx >> 6, col = idx & 63;
-        o[idx] = Lg[row][col];
-        ot[idx] = Lg[col][row];
-      }
-    }
-    __syncthreads();  // Lg is refilled by the next pass
   }
   CH_STAMP();  // inverses done
 #undef CH_STAMP
 }
 
-template <int NW>
+// workgroup 0: the chain; with HELP (grid of 17) workgroups 8 and 16 are its helpers, the
+// others leave at once
+template <int NW, bool HELP>
 __global__ __launch_bounds__(64 * NW) void k_diag_chain(double *K, int64_t ldk, int c0, int nb,
                                                      double *__restrict__ dvec,
                                                      double *__restrict__ dinv,
                                                      int *__restrict__ flags,
                                                      double *__restrict__ Linv,
                                                      double *__restrict__ LinvT,
-                                                     long long *__restrict__ dbg) {
+                                                     long long *__restrict__ dbg, int *hc,
+                                                     int epoch) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[CH_SMEM];
-  chain_body<NW>(smem, K, ldk, c0, nb, dvec, dinv, flags, Linv, LinvT, dbg);
+  if (blockIdx.x == 0) {
+    chain_body<NW, HELP>(smem, K, ldk, c0, nb, dvec, dinv, flags, Linv, LinvT, dbg, hc, epoch);
+  } else if (HELP && blockIdx.x == 8) {
+    helper_tiles<NW>(smem, K, ldk, c0, nb, dvec, hc, epoch, flags);
+  } else if (HELP && blockIdx.x == 16) {
+    helper_inverses<NW>(smem, K, ldk, c0, nb, hc, epoch, flags, Linv, LinvT);
+  }
 }
 
 // ------------------------------------------------------------------ D(k + 1) beside U(k)
-// ONE launch: workgroup 0 is the chain D(k + 1) of the next outer block; every other workgroup
-// updates four 64 x 64 tiles of block k's trailing update U(k) below the next diagonal block
-// (rows [row0, nrows) x columns [col0, colEnd), lower triangle; update_tile of the
-// k_ldlt_update kernel, one tile per group of four wavefronts, each group with its own LDS
-// slice).  The two roles touch disjoint cache lines and hand nothing to each other, so the
-// launch is correct whatever order the workgroups run in; dispatched first, the chain has its
-// CU to itself (its LDS footprint keeps other workgroups off) and runs in the shadow of the
-// update -- look-ahead without a second queue (which broke results in round 1) and without
-// hipExtAnyOrderLaunch (which on this stack starts the kernel early but not concurrently).
+// ONE launch: workgroup 0 is the chain D(k + 1) of the next outer block (workgroups 8 and 16
+// its helpers); every other workgroup updates one 128 x 128 tile of block k's trailing update
+// U(k) below the next diagonal block (rows [row0, nrows) x columns [col0, colEnd), lower
+// triangle; update_tile of the k_ldlt_update kernel).  The two roles touch disjoint cache lines
+// and hand nothing to each other, so the launch is correct whatever order the workgroups run
+// in; dispatched first, the chain has its CU from the start.
+template <bool HELP>
 __global__ __launch_bounds__(1024) void k_chain_update(double *K, int64_t ldk, int c0, int nb,
                                                        double *__restrict__ dvec,
                                                        double *__restrict__ dinv,
                                                        int *__restrict__ flags,
                                                        double *__restrict__ Linv,
-                                                       double *__restrict__ LinvT,
-                                                       long long *__restrict__ dbg,
-                                                       const double *W, int64_t ldw, int N,
-                                                       int nrows, int row0, int col0, int colEnd,
-                                                       int kc0, int KB) {
+                                                       double *__restrict__ LinvT, int *hc,
+                                                       int epoch, const double *W, int64_t ldw,
+                                                       int N, int nrows, int row0, int col0,
+                                                       int colEnd, int kc0, int KB) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[CH_SMEM];
-  if (blockIdx.x == 0) {
-    chain_body<16>(smem, K, ldk, c0, nb, dvec, dinv, flags, Linv, LinvT, dbg);
+  const int b = (int)blockIdx.x;
+  if (b == 0) {
+    chain_body<16, HELP>(smem, K, ldk, c0, nb, dvec, dinv, flags, Linv, LinvT, nullptr, hc, epoch);
     return;
   }
-  int t = (int)blockIdx.x - 1;
+  if (HELP && b == 8) {
+    helper_tiles<16>(smem, K, ldk, c0, nb, dvec, hc, epoch, flags);
+    return;
+  }
+  if (HELP && b == 16) {
+    helper_inverses<16>(smem, K, ldk, c0, nb, hc, epoch, flags, Linv, LinvT);
+    return;
+  }
   // linear tile id -> (tile row by, tile column bx): row by holds the tiles not entirely
   // above the diagonal.  ONE 128 x 128 tile per workgroup, 16 wavefronts as 4 x 4 with 2 x 2
   // MFMA tiles each and two LDS stages: the chain's LDS footprint allows one workgroup per CU,
   // so the 16 wavefronts share one staged panel pair instead of staging four 64 x 64 tiles'
-  // panels separately (227 -> ? us on the first block, where the update decides the launch).
+  // panels separately (227 -> 189 us on the first block, where the update decides the launch).
+  int t = b - 1 - (HELP ? (b > 8) + (b > 16) : 0);
   const int tr = (nrows - row0 + 127) / 128, tc = (colEnd - col0 + 127) / 128;
   int by = 0;
   while (by < tr) {
@@ -796,6 +997,21 @@ static int trsm_rows() {
   static const int r = (getenv("PGF_TRSM_ROWS") && atoi(getenv("PGF_TRSM_ROWS")) == 32) ? 32 : 16;
   return r;
 }
+
+// helper workgroups of the diagonal chain (PGF_CHAIN_HELP=0: the chain does everything itself);
+// switched off for the process after a failed placement check or a timed-out hand-over
+static bool g_help_off = false;
+static bool chain_helpers() {
+  static const bool on = !(getenv("PGF_CHAIN_HELP") && atoi(getenv("PGF_CHAIN_HELP")) == 0);
+  return on && !g_help_off;
+}
+void ldlt_chain_helpers_off() { g_help_off = true; }
+bool ldlt_chain_helpers_enabled() { return chain_helpers(); }
+void ldlt_chain_helpers_set(bool on) { g_help_off = !on; }
+
+// test hook (pgf_debug_fail_next_helper): make the factorisation just enqueued look like one
+// whose helpers failed their checks
+__global__ void k_helper_inject(int *__restrict__ flags) { atomicOr(&flags[2], 1); }
 
 static bool fused() {
   static const bool on = !(getenv("PGF_FUSED") && atoi(getenv("PGF_FUSED")) == 0);
@@ -846,15 +1062,27 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
   };
   PgfProfile dummy;
   PgfProfile &pr = p ? *p : dummy;
+  const bool help = chain_helpers();
   auto launch_d = [&](int c0) {
     span_begin(pr.chain_spans);
     long long *dbg = (c0 == 0) ? chain_dbg_buffer() : nullptr;
-    if (chain_waves() == 16)
-      hipLaunchKernelGGL(k_diag_chain<16>, dim3(1), dim3(1024), 0, s, f.K, f.ldk, c0,
-                         std::min(OB, N - c0), f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, dbg);
-    else
-      hipLaunchKernelGGL(k_diag_chain<8>, dim3(1), dim3(512), 0, s, f.K, f.ldk, c0,
-                         std::min(OB, N - c0), f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, dbg);
+    const int nb = std::min(OB, N - c0);
+    const int ep = ++f.help_epoch;
+    if (chain_waves() == 16) {
+      if (help)
+        hipLaunchKernelGGL((k_diag_chain<16, true>), dim3(17), dim3(1024), 0, s, f.K, f.ldk, c0, nb,
+                           f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, dbg, f.hctl, ep);
+      else
+        hipLaunchKernelGGL((k_diag_chain<16, false>), dim3(1), dim3(1024), 0, s, f.K, f.ldk, c0, nb,
+                           f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, dbg, f.hctl, ep);
+    } else {
+      if (help)
+        hipLaunchKernelGGL((k_diag_chain<8, true>), dim3(17), dim3(512), 0, s, f.K, f.ldk, c0, nb,
+                           f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, dbg, f.hctl, ep);
+      else
+        hipLaunchKernelGGL((k_diag_chain<8, false>), dim3(1), dim3(512), 0, s, f.K, f.ldk, c0, nb,
+                           f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, dbg, f.hctl, ep);
+    }
     span_end(pr.chain_spans);
   };
   auto launch_t = [&](int c0, double *Wb) {
@@ -893,9 +1121,15 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
       for (int by = 0; by < tr; ++by) ntiles += std::min(tc, (row0 + 128 * by + 127 - c1) / 128 + 1);
     }
     if (fused() && !p && ntiles > 0) {
-      hipLaunchKernelGGL(k_chain_update, dim3(1 + ntiles), dim3(1024), 0, s, f.K, f.ldk, c1,
-                         nb1, f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, (long long *)nullptr, Wb, ldw,
-                         N, nrows, row0, c1, N, c0, OB);
+      const int ep = ++f.help_epoch;
+      if (help)
+        hipLaunchKernelGGL(k_chain_update<true>, dim3(std::max(17, ntiles + 3)), dim3(1024), 0, s,
+                           f.K, f.ldk, c1, nb1, f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, f.hctl, ep,
+                           Wb, ldw, N, nrows, row0, c1, N, c0, OB);
+      else
+        hipLaunchKernelGGL(k_chain_update<false>, dim3(1 + ntiles), dim3(1024), 0, s, f.K, f.ldk,
+                           c1, nb1, f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, f.hctl, ep, Wb, ldw,
+                           N, nrows, row0, c1, N, c0, OB);
     } else {
       launch_d(c1);
       launch_update(f, s, Wb, ldw, N, nrows, row0, c1, N, c0, OB, p, 0);
@@ -903,6 +1137,10 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
     launch_t(c1, f.W + (size_t)(buf ^ 1) * f.wstride);
   }
   if (p) (void)hipEventRecord(p->factor_spans.back().second, s);
+  if (f.inject_helper_failure) {
+    f.inject_helper_failure = 0;
+    hipLaunchKernelGGL(k_helper_inject, dim3(1), dim3(1), 0, s, f.flags);
+  }
   e = hipMemcpyAsync(f.h_flags, f.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s);
   if (e != hipSuccess) return e;
   return hipGetLastError();

@@ -38,10 +38,12 @@ struct DenseLdlt {
   double *zwork = nullptr;  // solve work vector (Nmax)
   double *Linv = nullptr;   // inverse of every 64 x 64 diagonal block of L, [block][row][64]
   double *LinvT = nullptr;  // the transposes
-  int *flags = nullptr;     // [0] zero-pivot flag, [1] negative pivots
+  int *flags = nullptr;     // [0] zero-pivot flag, [1] negative pivots, [2] chain helpers failed
   // chained solves: [0, S) backward stamps, [S, 2S) forward stamps, [2S] XCC slot, [2S+1] bad
   int *chain = nullptr;
   int chain_stride = 0, chain_epoch = 0;
+  int *hctl = nullptr;      // stamps between the diagonal chain and its helper workgroups
+  int help_epoch = 0;
   int *h_flags = nullptr;   // pinned host mirror ([3]: status word of the chained solves)
   hipStream_t stream = nullptr;
   int OB = 256;             // outer block width (K-depth of the bulk trailing update)
@@ -51,13 +53,15 @@ struct DenseLdlt {
   int n_neg = 0;
   PgfProfile *prof = nullptr;
   int inject_chain_failure = 0;  // test hook: the next chained solve reports a failure
+  int inject_helper_failure = 0;  // test hook: the next factorisation reports failed helpers
 };
 
 hipError_t ldlt_alloc(DenseLdlt &f, int Nmax, hipStream_t stream);
 void ldlt_free(DenseLdlt &f);
 // enqueue the factorisation of the leading N x N lower triangle (+ rows up to nrows)
 hipError_t ldlt_factor_async(DenseLdlt &f, int N, int nrows);
-// wait and read flags: returns 0 ok / 1 singular; sets f.n_neg.  (A chained solve that failed
+// wait and read flags: returns 0 ok / 1 singular / 2 the diagonal chain's helper workgroups
+// failed their checks (they are switched off, factorise again); sets f.n_neg.  (A chained solve that failed
 // its own checks is reported by ldlt_chain_check after any host synchronisation.)
 int ldlt_finish(DenseLdlt &f, hipError_t *err);
 // sol <- K^{-1} rhs on device vectors of length N (rhs preserved if rhs != sol)
@@ -69,6 +73,9 @@ int ldlt_chain_check(DenseLdlt &f);
 void ldlt_chain_set_enabled(bool on);  // test hook: undo the switch-off of a failed check
 // look-ahead schedule (pgf_factor2.hip): the default; PGF_FACTOR=1 selects the round-1 one
 bool ldlt_use_lookahead();
+void ldlt_chain_helpers_off();
+bool ldlt_chain_helpers_enabled();     // helpers requested (PGF_CHAIN_HELP) and not switched off
+void ldlt_chain_helpers_set(bool on);  // test hook: undo / force the switch-off
 hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows);
 void ldlt_chain_timing_dump();  // PGF_CHAIN_TIMING diagnostic
 // shared launch helpers (pgf_ldlt.hip)

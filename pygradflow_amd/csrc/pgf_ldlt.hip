@@ -1225,6 +1225,8 @@ hipError_t ldlt_alloc(DenseLdlt &f, int Nmax, hipStream_t stream) {
   f.chain_stride = (int)(rows / 64 + 2);
   if ((e = hipMalloc(&f.chain, (2 * f.chain_stride + 4) * sizeof(int))) != hipSuccess) return e;
   if ((e = hipMemset(f.chain, 0, (2 * f.chain_stride + 4) * sizeof(int))) != hipSuccess) return e;
+  if ((e = hipMalloc(&f.hctl, 16 * sizeof(int))) != hipSuccess) return e;
+  if ((e = hipMemset(f.hctl, 0, 16 * sizeof(int))) != hipSuccess) return e;
   if ((e = hipHostMalloc(&f.h_flags, 4 * sizeof(int))) != hipSuccess) return e;
   for (int i = 0; i < 4; ++i) f.h_flags[i] = 0;
   return hipSuccess;
@@ -1240,6 +1242,7 @@ void ldlt_free(DenseLdlt &f) {
   if (f.LinvT) (void)hipFree(f.LinvT);
   if (f.flags) (void)hipFree(f.flags);
   if (f.chain) (void)hipFree(f.chain);
+  if (f.hctl) (void)hipFree(f.hctl);
   if (f.h_flags) (void)hipHostFree(f.h_flags);
   f = DenseLdlt();
 }
@@ -1349,9 +1352,15 @@ int ldlt_finish(DenseLdlt &f, hipError_t *err) {
   hipError_t e = hipStreamSynchronize(f.stream);
   if (err) *err = e;
   if (e != hipSuccess) return -1;
+  ldlt_chain_timing_dump();  // no-op unless PGF_CHAIN_TIMING is set
+  if (f.h_flags[2]) {  // the diagonal chain's helpers failed a check: nothing of this factor is
+    f.h_flags[2] = 0;  // to be trusted; they are off from now on and the caller factorises again
+    ldlt_chain_helpers_off();
+    f.factored = false;
+    return 2;
+  }
   f.n_neg = f.h_flags[1];
   f.factored = (f.h_flags[0] == 0);
-  ldlt_chain_timing_dump();  // no-op unless PGF_CHAIN_TIMING is set
   return f.h_flags[0] ? 1 : 0;
 }
 
