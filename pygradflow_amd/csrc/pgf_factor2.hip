@@ -138,127 +138,125 @@ __global__ __launch_bounds__(4 * TS * TS / 16) void k_update_diag(double *K, int
 }
 
 // ------------------------------------------------------------------ T(k)
-// Rows below outer block [c0, c0 + nb): workgroup g owns rows r0 = c0 + nb + 64 g ... + 63
-// (row N, a carried right-hand side, included).  Per 64-column sub-panel s, left-looking:
+// Rows below outer block [c0, c0 + nb): workgroup g owns the 16 rows r0 = c0 + nb + 16 g ...
+// (row N, a carried right-hand side, included), wavefront wc the columns 16 wc ... of every
+// 64-column sub-panel.  Per sub-panel s, left-looking:
 //   T_s = K[rows, sub-panel s] - sum_{t < s} X_t L_st^T ;  X_s = T_s inv(L_ss)^T
 //   W[rows, 64 s ..] = X_s (= L D) ;  K[rows, sub-panel s] = X_s D^-1 (= L)
-// The workgroup's whole 64 x 256 strip starts in registers (one 16 x 16 accumulator per
-// wavefront and sub-panel), the X_t it produces stay in LDS as the A operands of the later
-// sub-panels, and the ten B tiles (L_10, inv_1, L_20, L_21, inv_2, ...) stream from the
-// L2-resident diagonal block through ONE LDS buffer with the next tile's loads in flight
-// behind the current tile's MFMAs.
-// RT rows per workgroup (4 wavefronts per 16 rows).  The MFMA work of a workgroup is RT x 256
-// x 256 flops on ONE CU's matrix pipes (0.3 TFLOP/s): 17 us at RT = 64, so RT = 16 and four
-// times as many workgroups (the B tiles come from L2 either way).
-template <int RT>
-__global__ __launch_bounds__(RT * 16) void k_trsm_block(double *K, int64_t ldk, double *W,
-                                                     int64_t ldw, int nrows, int c0, int nb,
-                                                     const double *__restrict__ dinv,
-                                                     const double *__restrict__ Linv) {
-  constexpr int NT = RT * 16;          // threads
-  constexpr int NQ = 2048 / NT;        // 16-byte pieces of a 64 x 64 B tile per thread
-  __shared__ __attribute__((aligned(16))) unsigned char smem[(3 * RT + 64) * C_LD * 8 + 256 * 8];
-  double(*Bs)[C_LD] = reinterpret_cast<double(*)[C_LD]>(smem + 3 * RT * C_LD * 8);
-  double *ds = reinterpret_cast<double *>(smem + (3 * RT + 64) * C_LD * 8);
-  auto Xs = [&](int t) { return reinterpret_cast<double(*)[C_LD]>(smem + (size_t)t * RT * C_LD * 8); };
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 2, wc = wave & 3, l15 = lane & 15, l4 = lane >> 4;
+// The workgroup's 16 x 256 strip starts in registers (one 16 x 16 accumulator per wavefront and
+// sub-panel); the X_t it produces stay in LDS as the A operands of the later sub-panels.
+// The B operands (L_10, inv_1, L_20, L_21, inv_2, ...: ten 64 x 64 tiles of the L2-resident
+// diagonal block) are NOT staged through LDS: with 16 rows per workgroup every B element
+// feeds exactly one wavefront, so each wavefront loads its own 16-row slice straight into MFMA
+// operand registers, three tiles ahead of their use, and the six update steps need no barrier
+// at all -- only the four solves exchange T_s / X_s through LDS.  (Staged through LDS with two
+// barriers per tile the kernel took 20 us, 1.0-1.6 us per step against 0.5 us of MFMA work: one
+// wavefront per SIMD has nothing to hide an LDS round trip behind.  Now 17-19 us: an update
+// step takes 0.5-0.6 us when its B slice has arrived, but 300 workgroups pulling the same
+// 320 KB each out of L2 -- ~100 MB per launch -- make the loads, not the MFMAs, the limit;
+// in-kernel stamps: 3.5 us of cold strip loads, ~11 us of steps.)
+// The k index of an MFMA step is free as long as A and B agree: step q of lane group l4 takes
+// k = 8 (q / 2) + 2 l4 + (q & 1), so that both operands come as aligned 16-byte pairs.
+// 16 rows per workgroup because the MFMA work of a workgroup runs on ONE CU's matrix pipes
+// (0.3 TFLOP/s): 64 rows took 34 us.
+__global__ __launch_bounds__(256) void k_trsm_block(double *K, int64_t ldk, double *W, int64_t ldw,
+                                                    int nrows, int c0, int nb,
+                                                    const double *__restrict__ dinv,
+                                                    const double *__restrict__ Linv) {
+  __shared__ __attribute__((aligned(16))) double Xs[4][16][C_LD];
+  __shared__ double ds[256];
+  const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
   const int bend = c0 + nb;
-  const int r0 = bend + RT * (int)blockIdx.x;
+  const int r0 = bend + 16 * (int)blockIdx.x;
   const int ns = (nb + 63) / 64;
-  // B tile of step (s, t): t < s: rows of sub-panel s of the factored diagonal block, columns
-  // of sub-panel t (L_st); t == s: the inverse of diagonal tile s
-  double2_t pb[NQ];
-  auto fetch_b = [&](int s_, int t_) {
+  constexpr int DEPTH = 3;
+  double2_t bq[DEPTH][8];
+  auto fetch_b = [&](double2_t (&dst)[8], int idx) {
+    // idx -> tile (s_, t_), s_ (s_ + 1) / 2 + t_ = idx; t_ < s_: L_st, t_ == s_: inv(L_ss)
+    const int s_ = (idx >= 6) ? 3 : (idx >= 3) ? 2 : (idx >= 1) ? 1 : 0;
+    const int t_ = idx - s_ * (s_ + 1) / 2;
+    if (idx >= 10 || s_ >= ns) return;
     const int cb = c0 + 64 * s_;
-    const int ncol = min(64, bend - cb);
+    const int row = 16 * wc + l15;
+    const bool ok = (t_ == s_) || row < min(64, bend - cb);
+    const double *src = (t_ == s_) ? Linv + (size_t)(cb / 64) * 4096 + row * 64
+                                   : K + (int64_t)(cb + row) * ldk + c0 + 64 * t_;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int p = q * NT + tid;
-      const int row = p >> 5, c2 = (p & 31) * 2;
-      double2_t b = (double2_t){0.0, 0.0};
-      if (t_ == s_)
-        b = *reinterpret_cast<const double2_t *>(Linv + (size_t)(cb / 64) * 4096 + row * 64 + c2);
-      else if (row < ncol)
-        b = *reinterpret_cast<const double2_t *>(K + (int64_t)(cb + row) * ldk + c0 + 64 * t_ + c2);
-      pb[q] = b;
-    }
+    for (int j = 0; j < 8; ++j)
+      dst[j] = ok ? *reinterpret_cast<const double2_t *>(src + 8 * j + 2 * l4) : (double2_t){0.0, 0.0};
   };
-  fetch_b(0, 0);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) fetch_b(bq[d], d);
   double4_t acc[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const int cb = c0 + 64 * s;
-    const int j = cb + 16 * wc + l15;
+    const int j = c0 + 64 * s + 16 * wc + l15;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int i = r0 + 16 * wr + l4 + 4 * r;
+      const int i = r0 + l4 + 4 * r;
       acc[s][r] = (i < nrows && j < bend) ? K[(int64_t)i * ldk + j] : 0.0;
     }
   }
-  for (int i = tid; i < 256; i += NT) ds[i] = (i < nb) ? dinv[c0 + i] : 0.0;
+  ds[tid] = (tid < nb) ? dinv[c0 + tid] : 0.0;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     if (s < ns) {
       const int cb = c0 + 64 * s;
       const int ncol = min(64, bend - cb);
 #pragma unroll
-      for (int t = 0; t <= s; ++t) {
-        __syncthreads();  // Bs free; the X tiles written so far are visible
+      for (int t = 0; t < s; ++t) {
+        const int idx = s * (s + 1) / 2 + t;  // compile-time after unrolling
+        double4_t a4 = acc[s];
+        double2_t av[8];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int p = q * NT + tid;
-          *reinterpret_cast<double2_t *>(&Bs[p >> 5][(p & 31) * 2]) = pb[q];
-        }
-        double(*St)[C_LD] = Xs(s < 3 ? s : 0);  // staging tile of the solve (s == 3: X_0 is dead)
-        if (t == s) {
+        for (int j = 0; j < 8; ++j) av[j] = *reinterpret_cast<const double2_t *>(&Xs[t][l15][8 * j + 2 * l4]);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) St[16 * wr + l4 + 4 * r][16 * wc + l15] = acc[s][r];
+        for (int j = 0; j < 8; ++j) {
+          a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[j].x, bq[idx % DEPTH][j].x, a4, 0, 0, 0);
+          a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[j].y, bq[idx % DEPTH][j].y, a4, 0, 0, 0);
         }
+        acc[s] = a4;
+        fetch_b(bq[idx % DEPTH], idx + DEPTH);  // the slot just emptied
+      }
+      {
+        // X[i][j] = sum_k T[i][k] inv[j][k]: T_s goes through LDS (every wavefront needs the
+        // whole 64-column row), X_s replaces it there
+        const int idx = s * (s + 1) / 2 + s;
+        double(*St)[C_LD] = Xs[s];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) St[l4 + 4 * r][16 * wc + l15] = acc[s][r];
         __syncthreads();
-        // next B tile: (s, t + 1) or (s + 1, 0)
-        if (t < s) fetch_b(s, t + 1);
-        else if (s + 1 < ns) fetch_b(s + 1, 0);
-        if (t < s) {
-          double(*Xa)[C_LD] = Xs(t);
-          double4_t a4 = acc[s];
-#pragma unroll 4
-          for (int ks = 0; ks < 64; ks += 4) {
-            const double a = -Xa[16 * wr + l15][ks + l4];
-            const double b = Bs[16 * wc + l15][ks + l4];
-            a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, a4, 0, 0, 0);
-          }
-          acc[s] = a4;
-        } else {
-          // X[i][j] = sum_k T[i][k] inv[j][k]
-          double4_t x = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-          for (int ks = 0; ks < 64; ks += 4) {
-            const double a = St[16 * wr + l15][ks + l4];
-            const double b = Bs[16 * wc + l15][ks + l4];
-            x = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, x, 0, 0, 0);
-          }
-          __syncthreads();  // all reads of T done: X replaces it
+        double4_t x = (double4_t){0.0, 0.0, 0.0, 0.0};
+        double2_t av[8];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) St[16 * wr + l4 + 4 * r][16 * wc + l15] = x[r];
-          __syncthreads();
-          for (int p = tid; p < RT * 32; p += NT) {
-            const int row = p >> 5, c2 = (p & 31) * 2;
-            const int r = r0 + row;
-            if (r >= nrows || c2 >= ncol) continue;
-            const double2_t w = *reinterpret_cast<const double2_t *>(&St[row][c2]);
-            double2_t l;
-            l.x = w.x * ds[64 * s + c2];
-            l.y = w.y * ds[64 * s + c2 + 1];
-            double *wp = W + (int64_t)r * ldw + 64 * s + c2;
-            double *kp = K + (int64_t)r * ldk + cb + c2;
-            if (c2 + 1 < ncol) {
-              *reinterpret_cast<double2_t *>(wp) = w;
-              *reinterpret_cast<double2_t *>(kp) = l;
-            } else {
-              wp[0] = w.x;
-              kp[0] = l.x;
-            }
+        for (int j = 0; j < 8; ++j) av[j] = *reinterpret_cast<const double2_t *>(&St[l15][8 * j + 2 * l4]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j].x, bq[idx % DEPTH][j].x, x, 0, 0, 0);
+          x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j].y, bq[idx % DEPTH][j].y, x, 0, 0, 0);
+        }
+        fetch_b(bq[idx % DEPTH], idx + DEPTH);
+        __syncthreads();  // all reads of T done: X replaces it
+#pragma unroll
+        for (int r = 0; r < 4; ++r) St[l4 + 4 * r][16 * wc + l15] = x[r];
+        __syncthreads();
+        for (int p = tid; p < 16 * 32; p += 256) {
+          const int row = p >> 5, c2 = (p & 31) * 2;
+          const int r = r0 + row;
+          if (r >= nrows || c2 >= ncol) continue;
+          const double2_t w = *reinterpret_cast<const double2_t *>(&St[row][c2]);
+          double2_t l;
+          l.x = w.x * ds[64 * s + c2];
+          l.y = w.y * ds[64 * s + c2 + 1];
+          double *wp = W + (int64_t)r * ldw + 64 * s + c2;
+          double *kp = K + (int64_t)r * ldk + cb + c2;
+          if (c2 + 1 < ncol) {
+            *reinterpret_cast<double2_t *>(wp) = w;
+            *reinterpret_cast<double2_t *>(kp) = l;
+          } else {
+            wp[0] = w.x;
+            kp[0] = l.x;
           }
         }
       }
@@ -993,10 +991,6 @@ static int chain_waves() {
   return nw;
 }
 
-static int trsm_rows() {
-  static const int r = (getenv("PGF_TRSM_ROWS") && atoi(getenv("PGF_TRSM_ROWS")) == 32) ? 32 : 16;
-  return r;
-}
 
 // helper workgroups of the diagonal chain (PGF_CHAIN_HELP=0: the chain does everything itself);
 // switched off for the process after a failed placement check or a timed-out hand-over
@@ -1090,12 +1084,8 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
     const int below = nrows - (c0 + nb);
     if (below > 0) {
       span_begin(pr.trsm_spans);
-      if (trsm_rows() == 32)
-        hipLaunchKernelGGL(k_trsm_block<32>, dim3((below + 31) / 32), dim3(512), 0, s, f.K, f.ldk, Wb,
-                           ldw, nrows, c0, nb, f.dinv, f.Linv);
-      else
-        hipLaunchKernelGGL(k_trsm_block<16>, dim3((below + 15) / 16), dim3(256), 0, s, f.K, f.ldk, Wb,
-                           ldw, nrows, c0, nb, f.dinv, f.Linv);
+      hipLaunchKernelGGL(k_trsm_block, dim3((below + 15) / 16), dim3(256), 0, s, f.K, f.ldk, Wb, ldw,
+                         nrows, c0, nb, f.dinv, f.Linv);
       span_end(pr.trsm_spans);
     }
   };
