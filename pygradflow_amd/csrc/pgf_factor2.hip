@@ -33,6 +33,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #define C_LD 66    // LDS row stride of 64-column tiles: conflict-free MFMA fragment reads
 #define C_WLD 18
@@ -936,6 +937,16 @@ __global__ __launch_bounds__(64 * NW) void k_diag_chain(double *K, int64_t ldk, 
 // triangle; update_tile of the k_ldlt_update kernel).  The two roles touch disjoint cache lines
 // and hand nothing to each other, so the launch is correct whatever order the workgroups run
 // in; dispatched first, the chain has its CU from the start.
+// Jobs of one lazy update launch: job q brings column block [col0, col0 + 256) -- rows from
+// rowstart (or the diagonal, whichever is lower) -- from "blocks < kc0 / 256 applied" to
+// "blocks < (kc0 + KB) / 256 applied"; its 128 x 128 tiles are numbered tile_begin[q] ...
+#define UPD_MAXJOBS 96
+struct UpdJobs {
+  int njobs;
+  int tile_begin[UPD_MAXJOBS + 1];
+  int col0[UPD_MAXJOBS], rowstart[UPD_MAXJOBS], kc0[UPD_MAXJOBS], KB[UPD_MAXJOBS];
+};
+
 template <bool HELP>
 __global__ __launch_bounds__(1024) void k_chain_update(double *K, int64_t ldk, int c0, int nb,
                                                        double *__restrict__ dvec,
@@ -943,9 +954,8 @@ __global__ __launch_bounds__(1024) void k_chain_update(double *K, int64_t ldk, i
                                                        int *__restrict__ flags,
                                                        double *__restrict__ Linv,
                                                        double *__restrict__ LinvT, int *hc,
-                                                       int epoch, const double *W, int64_t ldw,
-                                                       int N, int nrows, int row0, int col0,
-                                                       int colEnd, int kc0, int KB) {
+                                                       int epoch, int N, int nrows,
+                                                       const UpdJobs jobs) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[CH_SMEM];
   const int b = (int)blockIdx.x;
   if (b == 0) {
@@ -960,23 +970,27 @@ __global__ __launch_bounds__(1024) void k_chain_update(double *K, int64_t ldk, i
     helper_inverses<16>(smem, K, ldk, c0, nb, hc, epoch, flags, Linv, LinvT);
     return;
   }
-  // linear tile id -> (tile row by, tile column bx): row by holds the tiles not entirely
-  // above the diagonal.  ONE 128 x 128 tile per workgroup, 16 wavefronts as 4 x 4 with 2 x 2
-  // MFMA tiles each and two LDS stages: the chain's LDS footprint allows one workgroup per CU,
-  // so the 16 wavefronts share one staged panel pair instead of staging four 64 x 64 tiles'
-  // panels separately (227 -> 189 us on the first block, where the update decides the launch).
+  // ONE 128 x 128 tile per workgroup, 16 wavefronts as 4 x 4 with 2 x 2 MFMA tiles each and
+  // two LDS stages: the chain's LDS footprint allows one workgroup per CU, so the 16 wavefronts
+  // share one staged panel pair instead of staging four 64 x 64 tiles' panels separately.
   int t = b - 1 - (HELP ? (b > 8) + (b > 16) : 0);
-  const int tr = (nrows - row0 + 127) / 128, tc = (colEnd - col0 + 127) / 128;
-  int by = 0;
-  while (by < tr) {
-    const int nc = min(tc, (row0 + 128 * by + 127 - col0) / 128 + 1);
-    if (t < nc) break;
-    t -= nc;
-    ++by;
+  if (t >= jobs.tile_begin[jobs.njobs]) return;
+  int q = 0;
+  while (t >= jobs.tile_begin[q + 1]) ++q;
+  t -= jobs.tile_begin[q];
+  const int col0 = jobs.col0[q], rs = jobs.rowstart[q];
+  // tile column 0, then tile column 1 of the block; rows from max(rowstart, column start)
+  int j0 = col0, i0 = max(rs, j0);
+  const int n0 = (nrows - i0 + 127) / 128;
+  if (t >= n0) {
+    t -= n0;
+    j0 = col0 + 128;
+    i0 = max(rs, j0);
   }
-  if (by >= tr) return;
-  update_tile<128, 128, 16, 4, 4, 1>(smem, threadIdx.x, row0 + 128 * by, col0 + 128 * t, K, ldk, W,
-                                     ldw, N, nrows, colEnd, kc0, KB);
+  i0 += 128 * t;
+  const int kc0 = jobs.kc0[q];
+  update_tile<128, 128, 16, 4, 4, 1, true>(smem, threadIdx.x, i0, j0, K, ldk, K + kc0, ldk, N, nrows,
+                                           N, kc0, jobs.KB[q], dvec + kc0);
 }
 
 // ------------------------------------------------------------------ host schedule
@@ -1006,6 +1020,23 @@ void ldlt_chain_helpers_set(bool on) { g_help_off = !on; }
 // test hook (pgf_debug_fail_next_helper): make the factorisation just enqueued look like one
 // whose helpers failed their checks
 __global__ void k_helper_inject(int *__restrict__ flags) { atomicOr(&flags[2], 1); }
+
+// budget of one lazy update launch in tile-blocks (128 x 128 tile x K-depth 256; 255 CUs take
+// one each per ~47 us) and the number of pending blocks an optional job may take at once;
+// PGF_LAZY_BUDGET=0: no limit = the eager schedule (every launch applies block k everywhere)
+static int lazy_budget() {
+  static const int b = getenv("PGF_LAZY_BUDGET") ? atoi(getenv("PGF_LAZY_BUDGET")) : 420;
+  return b > 0 ? b : (1 << 30);
+}
+// average tile-blocks per launch above which the factorisation counts as update-bound
+static int lazy_share_max() {
+  static const int v = getenv("PGF_LAZY_SHARE") ? atoi(getenv("PGF_LAZY_SHARE")) : 350;
+  return v;
+}
+static int lazy_cap() {
+  static const int c = getenv("PGF_LAZY_CAP") ? std::max(1, atoi(getenv("PGF_LAZY_CAP"))) : 2;
+  return c;
+}
 
 static bool fused() {
   static const bool on = !(getenv("PGF_FUSED") && atoi(getenv("PGF_FUSED")) == 0);
@@ -1089,6 +1120,30 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
       span_end(pr.trsm_spans);
     }
   };
+  // Lazy trailing update (production): column block J is only kept complete when the chain
+  // is about to need it; how far beyond that a launch goes is a budget, so that the work hides
+  // behind the chain instead of piling up in the first launches (U(0) alone took 189 us beside
+  // a 105 us chain).  done[J] = blocks [0, done[J]) have been applied to column block J.
+  // Only where the chain is the bound: when the update work per launch exceeds what hides
+  // behind a chain (large N: at N = 9800 the updates are 7 of 12 ms) every deferral ends as a
+  // few very deep tiles on a few CUs (measured 27 instead of 12 ms per step), so there every
+  // launch applies its block everywhere (`eager`, the same code with no budget).
+  const bool lazy = fused() && !p;
+  const int nblk = (N + OB - 1) / OB;
+  std::vector<int> done(nblk + 2, 0);
+  bool eager = false;
+  if (lazy && nblk > 1) {
+    long long total = 0;  // tile-blocks of the whole factorisation
+    for (int J = 1; J < nblk; ++J) {
+      long long n = 0;
+      for (int c = 0; c < 2; ++c) {
+        const int j0 = J * OB + 128 * c;
+        if (j0 < N) n += (nrows - j0 + 127) / 128;
+      }
+      total += n * J;
+    }
+    eager = total / (nblk - 1) > lazy_share_max();
+  }
   int buf = 0;
   if (N > 0) {
     launch_d(0);
@@ -1102,27 +1157,81 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
     hipLaunchKernelGGL(k_update_diag<32>, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, f.K, f.ldk, Wb,
                        ldw, c0, OB, c1, nb1);
     span_end(pr.udiag_spans);
-    // D(k + 1) and everything of U(k) below the next diagonal block, in one launch; while
-    // profiling (per-kernel events) and on request (PGF_FUSED=0) as two launches
+    // D(k + 1) beside trailing-update work, in one launch; while profiling (per-kernel events)
+    // and on request (PGF_FUSED=0) D(k + 1) and the whole of U(k) as two launches
     const int row0 = c1 + nb1;
-    int ntiles = 0;
-    if (row0 < nrows) {
-      const int tr = (nrows - row0 + 127) / 128, tc = (N - c1 + 127) / 128;
-      for (int by = 0; by < tr; ++by) ntiles += std::min(tc, (row0 + 128 * by + 127 - c1) / 128 + 1);
-    }
-    if (fused() && !p && ntiles > 0) {
+    if (lazy) {
+      const int k = c0 / OB;
+      UpdJobs jb;
+      jb.njobs = 0;
+      int units = 0, cnt[UPD_MAXJOBS];
+      auto tiles = [&](int col0, int rowstart) {
+        int n = 0;
+        for (int c = 0; c < 2; ++c) {
+          const int j0 = col0 + 128 * c;
+          if (j0 >= N) continue;
+          const int i0 = std::max(rowstart, j0);
+          if (i0 < nrows) n += (nrows - i0 + 127) / 128;
+        }
+        return n;
+      };
+      auto add = [&](int J, int rowstart, int p0, int p1) {
+        const int n = tiles(J * OB, rowstart);
+        if (!n) return;
+        const int q = jb.njobs++;
+        jb.col0[q] = J * OB;
+        jb.rowstart[q] = rowstart;
+        jb.kc0[q] = p0 * OB;
+        jb.KB[q] = (p1 - p0 + 1) * OB;
+        cnt[q] = n;
+        units += n * (p1 - p0 + 1);
+      };
+      // needed by T(k + 1): the rows below diagonal block k + 1 (its diagonal block has had
+      // everything but block k since the previous launch, and block k from k_update_diag)
+      const int budget = eager ? (1 << 30) : lazy_budget();
+      const int cap = lazy_cap();
+      if (done[k + 1] <= k) add(k + 1, row0, done[k + 1], k);
+      done[k + 1] = k + 1;
+      // needed by k_update_diag (k + 2) / D(k + 2): column block k + 2 complete through block k;
+      // beyond that as far as the budget goes, nearest column block first, at most `cap`
+      // pending blocks per job (a job's tiles are one workgroup each, K-depth 256 per block)
+      for (int J = k + 2; J < nblk; ++J) {
+        const int pend = k + 1 - done[J];
+        if (pend <= 0) continue;
+        const bool mand = (J == k + 2);
+        if (!mand && (units >= budget || jb.njobs >= UPD_MAXJOBS)) break;
+        const int take = mand ? pend : std::min(pend, cap);
+        add(J, J * OB, done[J], done[J] + take - 1);
+        done[J] += take;
+      }
+      // deepest jobs first: their tiles take longest
+      int order[UPD_MAXJOBS];
+      for (int q = 0; q < jb.njobs; ++q) order[q] = q;
+      std::stable_sort(order, order + jb.njobs, [&](int a, int b) { return jb.KB[a] > jb.KB[b]; });
+      UpdJobs js;
+      js.njobs = jb.njobs;
+      js.tile_begin[0] = 0;
+      for (int q = 0; q < jb.njobs; ++q) {
+        const int o = order[q];
+        js.col0[q] = jb.col0[o];
+        js.rowstart[q] = jb.rowstart[o];
+        js.kc0[q] = jb.kc0[o];
+        js.KB[q] = jb.KB[o];
+        js.tile_begin[q + 1] = js.tile_begin[q] + cnt[o];
+      }
+      const int ntiles = js.tile_begin[js.njobs];
       const int ep = ++f.help_epoch;
       if (help)
         hipLaunchKernelGGL(k_chain_update<true>, dim3(std::max(17, ntiles + 3)), dim3(1024), 0, s,
                            f.K, f.ldk, c1, nb1, f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, f.hctl, ep,
-                           Wb, ldw, N, nrows, row0, c1, N, c0, OB);
+                           N, nrows, js);
       else
         hipLaunchKernelGGL(k_chain_update<false>, dim3(1 + ntiles), dim3(1024), 0, s, f.K, f.ldk,
-                           c1, nb1, f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, f.hctl, ep, Wb, ldw,
-                           N, nrows, row0, c1, N, c0, OB);
+                           c1, nb1, f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, f.hctl, ep, N, nrows,
+                           js);
     } else {
       launch_d(c1);
-      launch_update(f, s, Wb, ldw, N, nrows, row0, c1, N, c0, OB, p, 0);
+      if (row0 < nrows) launch_update(f, s, Wb, ldw, N, nrows, row0, c1, N, c0, OB, p, 0);
     }
     launch_t(c1, f.W + (size_t)(buf ^ 1) * f.wstride);
   }

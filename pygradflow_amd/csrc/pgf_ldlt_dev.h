@@ -57,12 +57,16 @@ __device__ __forceinline__ double fast_recip(double d) {
 
 // BM x BN = tile (rows x columns); BK = K-chunk staged per barrier pair; 4 wavefronts as
 // 2 x 2, each (BM/2) x (BN/2) = TM x TN MFMA tiles.  LDS rows are padded to BK + 2 doubles.
-template <int BM, int BN, int BK, int WR = 2, int WC = 2, int DB = 0>
+// SCALE: the A operand is L itself (W points into K) and is multiplied by D (dsc[k], k from the
+// first column of the K-range) while it is staged: W = L D of ANY earlier block, not only of
+// the one whose W panel is still in its buffer (the lazy schedule of pgf_factor2.hip).
+template <int BM, int BN, int BK, int WR = 2, int WC = 2, int DB = 0, bool SCALE = false>
 __device__ __forceinline__ void update_tile(unsigned char *smem, const int tid, const int i0,
                                             const int j0,
                                             double *__restrict__ K, int64_t ldk,
                                             const double *__restrict__ W, int64_t ldw, int N,
-                                            int nrows, int colEnd, int kc0, int KBc) {
+                                            int nrows, int colEnd, int kc0, int KBc,
+                                            const double *__restrict__ dsc = nullptr) {
   const int KB = KBc;  // K-depth
   const int coh = 0;
   constexpr int NT = 64 * WR * WC;           // threads per workgroup
@@ -99,7 +103,7 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int tid, 
   }
 
   // staging map: piece p = q*256 + tid -> row p / PPR, two doubles at column (p % PPR)*2
-  double2_t pa[PA], pb[PB];
+  double2_t pa[PA], pb[PB], pd[SCALE ? PA : 1];
   auto fetch = [&](int kk, int = 0) {
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
@@ -109,6 +113,7 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int tid, 
       double2_t va = (double2_t){0.0, 0.0};
       if (gi < nrows) va = ld_f64x2(W + (int64_t)gi * ldw + kk + kofs, coh);
       pa[q] = va;
+      if (SCALE) pd[q] = *reinterpret_cast<const double2_t *>(dsc + kk + kofs);
     }
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
@@ -129,7 +134,7 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int tid, 
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
       const int p = q * NT + tid;
-      *reinterpret_cast<double2_t *>(&As[p / PPR][(p % PPR) * 2]) = -pa[q];
+      *reinterpret_cast<double2_t *>(&As[p / PPR][(p % PPR) * 2]) = SCALE ? -pa[q] * pd[q] : -pa[q];
     }
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
