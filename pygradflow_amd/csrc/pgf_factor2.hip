@@ -38,8 +38,8 @@
 #define C_LD 66    // LDS row stride of 64-column tiles: conflict-free MFMA fragment reads
 #define C_WLD 18
 #define CH_ROWS 256
-// M[256][66] | Wt[2][64][18] | D[64] | 1/D[64] | flag
-#define CH_SMEM (CH_ROWS * C_LD * 8 + 2 * 64 * C_WLD * 8 + 2 * 64 * 8 + 16)
+// M[256][66] | Wt[2][64][18] | D[64] | 1/D[64] | flag | 1/D of the previous sub-panel [64]
+#define CH_SMEM (CH_ROWS * C_LD * 8 + 2 * 64 * C_WLD * 8 + 3 * 64 * 8 + 16)
 
 // ------------------------------------------------------------------ TS x TS tile product
 // One 16 x 16 MFMA tile per wavefront of a (TS / 16)^2-wavefront workgroup:
@@ -470,7 +470,8 @@ __device__ __forceinline__ double ld_agent(const double *p) {
 __device__ __forceinline__ void invert_tile(unsigned char *smem, const double *K, int64_t ldk,
                                             int b0, int nbw, bool live, double *__restrict__ Linv,
                                             double *__restrict__ LinvT) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // wave: uniform per wavefront -> scalar register, role tests and tile numbers on the SALU
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4, v = wave & 3;
   double(*Lg)[C_LD] = reinterpret_cast<double(*)[C_LD]>(smem + (size_t)(wave >> 2) * 64 * C_LD * 8);
   if (live) {
@@ -568,7 +569,8 @@ __device__ __forceinline__ void helper_tiles(unsigned char *smem, double *K, int
   constexpr int NT = 64 * NW;
   double(*Mh)[C_LD] = reinterpret_cast<double(*)[C_LD]>(smem);
   double *dDs = reinterpret_cast<double *>(smem + 128 * C_LD * 8);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // wave: uniform per wavefront -> scalar register, role tests and tile numbers on the SALU
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
   const int bend = c0 + nb, ns = (nb + 63) / 64;
   if (tid == 0) help_check_xcc(hc, epoch, flags);
@@ -643,7 +645,8 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
   double *dI = dD + 64;
   int &s_bad = *reinterpret_cast<int *>(dI + 64);
   constexpr int NT = 64 * NW;  // NW = 16 or 8 wavefronts (8: 256 registers per lane)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // wave: uniform per wavefront -> scalar register, role tests and tile numbers on the SALU
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
   const int bend = c0 + nb;
   const int ns = (nb + 63) / 64;
@@ -656,13 +659,22 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
   CH_STAMP();
   if (HELP && tid == 0) help_check_xcc(hc, epoch, flags);
 
-  bool preloaded = false;
+  bool preloaded = false, early0 = false;
+  double *dIo = dI + 64 + 2;  // 1/D of the sub-panel just factored (behind the flag word)
   for (int s = 0; s < ns; ++s) {
+    // Thread and wavefront indices are laundered once per sub-panel: otherwise every address
+    // and role predicate of the loop body is hoisted to the kernel entry and kept alive across
+    // the eliminations, where a lane has no register to spare (128 in a 16-wavefront workgroup):
+    // 60 spilled registers, and a first scratch access costs microseconds.
+    int tl_ = threadIdx.x, wv_ = wave;
+    asm volatile("" : "+v"(tl_), "+s"(wv_));
+    const int tid = tl_, lane = tid & 63, wave = wv_;
+    const int l15 = lane & 15, l4 = lane >> 4;
     const int cb = c0 + 64 * s;
     const int ncol = min(64, bend - cb);
     const int own = max(0, bend - cb - 64);  // block rows below the tile (ncol == 64 if any)
     const int ownp = (own + 63) & ~63;       // padded to whole wavefronts of rows
-    if (tid == 0) s_bad = 0;
+    if (tid == 0 && !early0) s_bad = 0;
     // ---- load the stack: diagonal tile (identity outside the valid lower triangle) + the
     // block's rows below, all loads of a lane in flight before its first LDS store.  Not for
     // a stack the previous sub-panel's in-block update has left in M already (see there).
@@ -720,7 +732,9 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
     };
     for (int sb = 0; sb < 4; ++sb) {
       if (wave == 0) {
-        chain_a_plus(M, Wt + (sb & 1) * 64, dD, dI, s_bad, lane, sb, ncol);
+        // (step 0 of a stack built in place has been eliminated beside the tail of the
+        // previous sub-panel's in-block update already)
+        if (!(early0 && sb == 0)) chain_a_plus(M, Wt + (sb & 1) * 64, dD, dI, s_bad, lane, sb, ncol);
       } else if (wave <= 3) {
         if (sb > 0 && 64 * (wave - 1) < own) chain_b_own(M, 64 * wave + lane, sb - 1, lane);
       } else {
@@ -741,6 +755,10 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
             own_tile(sb - 2, 4 + e % ot, sb + e / ot);
           }
         }
+        // helper T has had three steps to finish what it was handed one sub-panel ago:
+        // everything this sub-panel's in-block update fetches after step 3
+        if (HELP && sb == 3 && tid == NT - 64 && s >= 1 && s + 1 < ns)
+          help_wait(hc + HC_DONE + s - 1, epoch, flags);
       }
       __syncthreads();
       if (s == 0) CH_STAMP();  // phase 1 of step sb
@@ -755,13 +773,6 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
       __syncthreads();
     }
     if (s == 0) CH_STAMP();  // four steps done
-    if (wave >= 1 && wave <= 3 && 64 * (wave - 1) < own) chain_b_own(M, 64 * wave + lane, 3, lane);
-    // helper T has had the whole sub-panel to finish what it was handed one sub-panel ago:
-    // everything this sub-panel's in-block update fetches below
-    if (HELP && tid == 0 && s >= 1 && s + 1 < ns) help_wait(hc + HC_DONE + s - 1, epoch, flags);
-    __syncthreads();
-    CH_STAMP();  // panel factored
-
     // ---- trailing update inside the block (rows / columns below the tile, K-depth 64, A = -X
     // from M, B = X D^-1): the C tiles live in global memory; ALL of a wavefront's tiles are
     // fetched in one burst here, so that their latency (they were last written by another
@@ -794,103 +805,227 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
     // whole 64-row tiles below (no ragged edge): the next stack is built in place
     const bool direct = own > 0 && (own & 63) == 0;
     double4_t ct[MT];
+    early0 = false;
+    if (HELP && NW == 16 && direct) {
+      // ---- With helpers and whole tiles the sub-panel boundary is pipelined:
+      //  A  wavefronts 1-3 finish the lagging rows (step 3); the others fetch their C sub-tiles
+      //     and write the factored tile, D, 1/D and the flags back meanwhile
+      //  B  L rows written back; first round of MFMA sub-tiles = the NEXT diagonal tile (plus
+      //     six others), which goes straight into M[0..63]; stamp to the helpers
+      //  C  wavefront 0 eliminates step 0 of the next sub-panel while the others finish the
+      //     remaining sub-tiles (in registers: M's rows 64.. are still their operands)
+      //  D  those go into M as the rest of the next stack
+      auto eidx = [&](int q) {  // sub-tile of round q: round 0 one per wavefront, then 1..15 only
+        if (q == 0) return wave;
+        return wave == 0 ? total : NW + (wave - 1) + (NW - 1) * (q - 1);
+      };
+      // (the C loads of wavefronts 1-3 are in flight while they finish the lagging rows)
 #pragma unroll
-    for (int q = 0; q < MT; ++q) {
-      const int e = wave + q * NW;
-      ct[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
-      if (e < total) {
-        int gi, gj, mi, mj;
-        decode(e, gi, gj, mi, mj);
-        const int j = gj + l15;
+      for (int q = 0; q < MT; ++q) {
+        const int e = eidx(q);
+        ct[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        if (e < total) {
+          int gi, gj, mi, mj;
+          decode(e, gi, gj, mi, mj);
+          const int j = gj + l15;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = gi + l4 + 4 * r;
-          if (i < bend && j < bend && j <= i)
-            ct[q][r] = HELP ? ld_agent(K + (int64_t)i * ldk + j) : K[(int64_t)i * ldk + j];
+          for (int r = 0; r < 4; ++r) ct[q][r] = ld_agent(K + (int64_t)(gi + l4 + 4 * r) * ldk + j);
         }
       }
-    }
-    // ---- write back: factored tile, D, 1/D, flags; rows below: L = X D^-1
-    for (int p = tid; p < 64 * 64; p += NT) {
-      const int row = p >> 6, c = p & 63;
-      if (row < ncol && c <= row) K[(int64_t)(cb + row) * ldk + cb + c] = M[row][c];
-    }
-    if (tid < ncol) {
-      dvec[cb + tid] = dD[tid];
-      dinv[cb + tid] = dI[tid];
-    }
-    if (wave == 0) {
-      const unsigned long long negs = __ballot(lane < ncol && dD[lane] < 0.0);
-      if (lane == 0) {
-        if (s_bad) atomicOr(&flags[0], 1);
-        const int neg = __popcll(negs);
-        if (neg) atomicAdd(&flags[1], neg);
+      if (s == 0) CH_STAMP();  // C loads issued
+      if (wave >= 1 && wave <= 3 && 64 * (wave - 1) < own) chain_b_own(M, 64 * wave + lane, 3, lane);
+      for (int p = tid; p < 64 * 64; p += NT) {
+        const int row = p >> 6, c = p & 63;
+        if (c <= row) K[(int64_t)(cb + row) * ldk + cb + c] = M[row][c];
       }
-    }
-    for (int p = tid; p < own * 32; p += NT) {
-      const int row = 64 + (p >> 5), c2 = (p & 31) * 2;
-      double2_t v = *reinterpret_cast<const double2_t *>(&M[row][c2]);
-      v.x *= dI[c2];
-      v.y *= dI[c2 + 1];
-      *reinterpret_cast<double2_t *>(K + (int64_t)(cb + row) * ldk + cb + c2) = v;
-    }
-    if (s == 0) CH_STAMP();  // written back
-#pragma unroll
-    for (int q = 0; q < MT; ++q) {
-      const int e = wave + q * NW;
-      if (e < total) {
-        int gi, gj, mi, mj;
-        decode(e, gi, gj, mi, mj);
-        {
+      if (s == 0) CH_STAMP();  // tile written back
+      if (tid < 64) {
+        dvec[cb + tid] = dD[tid];
+        dinv[cb + tid] = dI[tid];
+        dIo[tid] = dI[tid];
+      }
+      if (wave == 0) {
+        const unsigned long long negs = __ballot(dD[lane] < 0.0);
+        if (lane == 0) {
+          if (s_bad) atomicOr(&flags[0], 1);
+          s_bad = 0;  // for the early step 0 below
+          const int neg = __popcll(negs);
+          if (neg) atomicAdd(&flags[1], neg);
+        }
+      }
+      if (s == 0) CH_STAMP();  // (wavefront 0) before the barrier
+      __syncthreads();  // A -> B
+      CH_STAMP();       // panel factored
+      for (int p = tid; p < own * 32; p += NT) {
+        const int row = 64 + (p >> 5), c2 = (p & 31) * 2;
+        double2_t v = *reinterpret_cast<const double2_t *>(&M[row][c2]);
+        v.x *= dIo[c2];
+        v.y *= dIo[c2 + 1];
+        *reinterpret_cast<double2_t *>(K + (int64_t)(cb + row) * ldk + cb + c2) = v;
+      }
+      auto mfma_sub = [&](int q) {
+        const int e = eidx(q);
+        if (e < total) {
+          int gi, gj, mi, mj;
+          decode(e, gi, gj, mi, mj);
           double4_t c = ct[q];
 #pragma unroll 4
           for (int ks = 0; ks < 64; ks += 4) {
             const double av = -M[mi + l15][ks + l4];
-            const double bv = M[mj + l15][ks + l4] * dI[ks + l4];
+            const double bv = M[mj + l15][ks + l4] * dIo[ks + l4];
             c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
           }
-          if (direct && mj < 128) {
-            ct[q] = c;  // next sub-panel's stack: stays in registers until M is free
-          } else {
-            const int j = gj + l15;
+          ct[q] = c;
+        }
+      };
+      auto to_stack = [&](int q) {  // sub-tile of round q -> its place in the next stack
+        const int e = eidx(q);
+        if (e < total) {
+          int gi, gj, mi, mj;
+          decode(e, gi, gj, mi, mj);
+          const int cj = mj - 64 + l15;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int i = gi + l4 + 4 * r;
-              if (i < bend && j < bend && j <= i) K[(int64_t)i * ldk + j] = c[r];
-            }
+          for (int r = 0; r < 4; ++r) {
+            const int ri = mi - 64 + l4 + 4 * r;
+            M[ri][cj] = (cj <= ri) ? ct[q][r] : 0.0;
+          }
+        }
+      };
+      if (s == 0) CH_STAMP();  // L rows written back
+      mfma_sub(0);
+      if (s == 0) CH_STAMP();  // first MFMA round
+      // rows 0..63 of M (the old tile) were last read by the write-back before A -> B
+      if (wave < 10) to_stack(0);
+      for (int p = tid; p < 6 * 256; p += NT) {  // the six sub-tiles above the new diagonal
+        const int t6 = p >> 8, rr = (p >> 4) & 15, cc = p & 15;
+        const int ti = (t6 >= 5) ? 2 : (t6 >= 3) ? 1 : 0;  // (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+        const int tj = (ti == 0) ? 1 + t6 : (ti == 1) ? t6 - 1 : 3;
+        M[16 * ti + rr][16 * tj + cc] = 0.0;
+      }
+      if (s == 0) CH_STAMP();  // next diagonal tile stored
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // write-backs have left
+      if (s == 0) CH_STAMP();  // stores drained
+      __syncthreads();  // B -> C
+      if (tid == 0) help_post(hc + HC_STAMP + s, epoch);
+      CH_STAMP();  // next diagonal tile in place
+      // (one barrier, reached on two paths: the branch is uniform per wavefront, and this way
+      // no accumulator of the other path is live across the elimination, which has no
+      // registers to spare)
+      if (wave == 0) {
+        chain_a_plus(M, Wt, dD, dI, s_bad, lane, 0, 64);
+        __syncthreads();  // C -> D
+      } else {
+#pragma unroll
+        for (int q = 1; q < MT; ++q) mfma_sub(q);
+        __syncthreads();  // C -> D: nobody reads the old rows 64.. of M any more
+        if (wave >= 10) to_stack(0);
+#pragma unroll
+        for (int q = 1; q < MT; ++q) to_stack(q);
+      }
+      preloaded = true;
+      early0 = true;
+    } else {
+      if (wave >= 1 && wave <= 3 && 64 * (wave - 1) < own) chain_b_own(M, 64 * wave + lane, 3, lane);
+      __syncthreads();
+      CH_STAMP();  // panel factored
+#pragma unroll
+      for (int q = 0; q < MT; ++q) {
+        const int e = wave + q * NW;
+        ct[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        if (e < total) {
+          int gi, gj, mi, mj;
+          decode(e, gi, gj, mi, mj);
+          const int j = gj + l15;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = gi + l4 + 4 * r;
+            if (i < bend && j < bend && j <= i)
+              ct[q][r] = HELP ? ld_agent(K + (int64_t)i * ldk + j) : K[(int64_t)i * ldk + j];
           }
         }
       }
-    }
-    if (HELP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // write-backs have left
-    __syncthreads();  // M is refilled next; the global tiles written above are read back
-    if (HELP && tid == 0) help_post(hc + HC_STAMP + s, epoch);
-    preloaded = direct;
-    if (direct) {
-      // the next sub-panel's stack (columns 64..127 of this one's rows 64..) goes from the
-      // accumulators straight into M: no round trip through global memory
+      // ---- write back: factored tile, D, 1/D, flags; rows below: L = X D^-1
+      for (int p = tid; p < 64 * 64; p += NT) {
+        const int row = p >> 6, c = p & 63;
+        if (row < ncol && c <= row) K[(int64_t)(cb + row) * ldk + cb + c] = M[row][c];
+      }
+      if (tid < ncol) {
+        dvec[cb + tid] = dD[tid];
+        dinv[cb + tid] = dI[tid];
+      }
+      if (wave == 0) {
+        const unsigned long long negs = __ballot(lane < ncol && dD[lane] < 0.0);
+        if (lane == 0) {
+          if (s_bad) atomicOr(&flags[0], 1);
+          const int neg = __popcll(negs);
+          if (neg) atomicAdd(&flags[1], neg);
+        }
+      }
+      for (int p = tid; p < own * 32; p += NT) {
+        const int row = 64 + (p >> 5), c2 = (p & 31) * 2;
+        double2_t v = *reinterpret_cast<const double2_t *>(&M[row][c2]);
+        v.x *= dI[c2];
+        v.y *= dI[c2 + 1];
+        *reinterpret_cast<double2_t *>(K + (int64_t)(cb + row) * ldk + cb + c2) = v;
+      }
+      if (s == 0) CH_STAMP();  // written back
 #pragma unroll
       for (int q = 0; q < MT; ++q) {
         const int e = wave + q * NW;
         if (e < total) {
           int gi, gj, mi, mj;
           decode(e, gi, gj, mi, mj);
-          if (mj < 128) {
-            const int cj = mj - 64 + l15;
+          {
+            double4_t c = ct[q];
+#pragma unroll 4
+            for (int ks = 0; ks < 64; ks += 4) {
+              const double av = -M[mi + l15][ks + l4];
+              const double bv = M[mj + l15][ks + l4] * dI[ks + l4];
+              c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
+            }
+            if (direct && mj < 128) {
+              ct[q] = c;  // next sub-panel's stack: stays in registers until M is free
+            } else {
+              const int j = gj + l15;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int ri = mi - 64 + l4 + 4 * r;
-              M[ri][cj] = (cj <= ri) ? ct[q][r] : 0.0;
+              for (int r = 0; r < 4; ++r) {
+                const int i = gi + l4 + 4 * r;
+                if (i < bend && j < bend && j <= i) K[(int64_t)i * ldk + j] = c[r];
+              }
             }
           }
         }
       }
-      // the six 16 x 16 sub-tiles above the diagonal of the new diagonal tile
-      for (int p = tid; p < 6 * 256; p += NT) {
-        const int t6 = p >> 8, rr = (p >> 4) & 15, cc = p & 15;
-        const int ti = (t6 >= 5) ? 2 : (t6 >= 3) ? 1 : 0;  // (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
-        const int tj = (ti == 0) ? 1 + t6 : (ti == 1) ? t6 - 1 : 3;
-        M[16 * ti + rr][16 * tj + cc] = 0.0;
+      if (HELP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // write-backs have left
+      __syncthreads();  // M is refilled next; the global tiles written above are read back
+      if (HELP && tid == 0) help_post(hc + HC_STAMP + s, epoch);
+      preloaded = direct;
+      if (direct) {
+        // the next sub-panel's stack (columns 64..127 of this one's rows 64..) goes from the
+        // accumulators straight into M: no round trip through global memory
+#pragma unroll
+        for (int q = 0; q < MT; ++q) {
+          const int e = wave + q * NW;
+          if (e < total) {
+            int gi, gj, mi, mj;
+            decode(e, gi, gj, mi, mj);
+            if (mj < 128) {
+              const int cj = mj - 64 + l15;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int ri = mi - 64 + l4 + 4 * r;
+                M[ri][cj] = (cj <= ri) ? ct[q][r] : 0.0;
+              }
+            }
+          }
+        }
+        // the six 16 x 16 sub-tiles above the diagonal of the new diagonal tile
+        for (int p = tid; p < 6 * 256; p += NT) {
+          const int t6 = p >> 8, rr = (p >> 4) & 15, cc = p & 15;
+          const int ti = (t6 >= 5) ? 2 : (t6 >= 3) ? 1 : 0;  // (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+          const int tj = (ti == 0) ? 1 + t6 : (ti == 1) ? t6 - 1 : 3;
+          M[16 * ti + rr][16 * tj + cc] = 0.0;
+        }
       }
     }
     CH_STAMP();  // in-block update done
