@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(1024) void k_chain_update(double *K, int64_t ldk, i
   }
   i0 += 128 * t;
   const int kc0 = jobs.kc0[q];
-  update_tile<128, 128, 16, 4, 4, 1, true>(smem, threadIdx.x, i0, j0, K, ldk, K + kc0, ldk, N, nrows,
+  update_tile<128, 128, 32, 4, 4, 1, true>(smem, threadIdx.x, i0, j0, K, ldk, K + kc0, ldk, N, nrows,
                                            N, kc0, jobs.KB[q], dvec + kc0);
 }
 
@@ -1163,11 +1163,6 @@ static int lazy_budget() {
   static const int b = getenv("PGF_LAZY_BUDGET") ? atoi(getenv("PGF_LAZY_BUDGET")) : 420;
   return b > 0 ? b : (1 << 30);
 }
-// average tile-blocks per launch above which the factorisation counts as update-bound
-static int lazy_share_max() {
-  static const int v = getenv("PGF_LAZY_SHARE") ? atoi(getenv("PGF_LAZY_SHARE")) : 350;
-  return v;
-}
 static int lazy_cap() {
   static const int c = getenv("PGF_LAZY_CAP") ? std::max(1, atoi(getenv("PGF_LAZY_CAP"))) : 2;
   return c;
@@ -1197,6 +1192,88 @@ void ldlt_chain_timing_dump() {
   fprintf(stderr, "k_diag_chain phase stamps (us since kernel start):");
   for (int i = 1; i < 32 && h[i]; ++i) fprintf(stderr, " %.2f", (double)(h[i] - h[0]) * 0.01);
   fprintf(stderr, "\n");
+}
+
+// ------------------------------------------------------------------ lazy update plan
+// The trailing update beside the chain.  Launch L (chain D(L), panels of blocks < L available)
+// must leave column block L complete below its diagonal block (T(L) reads it) and column block
+// L + 1 complete through block L - 1 (k_update_diag / D(L + 1)); every other (column block,
+// block) pair may wait.  Work is counted in tile-blocks (one 128 x 128 tile x K-depth 256 =
+// one workgroup for ~45 us); what hides behind a chain of ~86 us is a little less than two
+// rounds over 255 CUs.  Earliest deadline first with a per-launch budget: nearest column block
+// first, an optional job takes at most `cap` pending blocks at once (its tiles run for cap x
+// 45 us).  Too small a budget pushes work against the deadlines, where it comes back as a few
+// very deep tiles on a few CUs; too large a one front-loads the launches as the eager schedule
+// does.  The budget is therefore chosen per factorisation: the candidate with the smallest
+// estimated total time (plan_cost) -- the reduced size changes from step to step.
+struct UpdPlan {
+  std::vector<UpdJobs> launch;  // [L - 1]
+  double cost = 0.0;            // estimated sum of launch times in units of one tile-block
+};
+
+static void plan_updates(UpdPlan &pl, int N, int nrows, int OB, int budget, int cap, double chain_units) {
+  const int nblk = (N + OB - 1) / OB;
+  std::vector<int> done(nblk + 2, 0);
+  pl.launch.assign(std::max(0, nblk - 1), UpdJobs());
+  pl.cost = 0.0;
+  auto tiles = [&](int col0, int rowstart) {
+    int n = 0;
+    for (int c = 0; c < 2; ++c) {
+      const int j0 = col0 + 128 * c;
+      if (j0 >= N) continue;
+      const int i0 = std::max(rowstart, j0);
+      if (i0 < nrows) n += (nrows - i0 + 127) / 128;
+    }
+    return n;
+  };
+  for (int k = 0; k + 1 < nblk; ++k) {
+    const int c1 = (k + 1) * OB, nb1 = std::min(OB, N - c1), row0 = c1 + nb1;
+    UpdJobs jb;
+    jb.njobs = 0;
+    int units = 0, maxdepth = 0, cnt[UPD_MAXJOBS];
+    auto add = [&](int J, int rowstart, int p0, int p1) {
+      const int n = tiles(J * OB, rowstart);
+      if (!n) return;
+      const int q = jb.njobs++;
+      jb.col0[q] = J * OB;
+      jb.rowstart[q] = rowstart;
+      jb.kc0[q] = p0 * OB;
+      jb.KB[q] = (p1 - p0 + 1) * OB;
+      cnt[q] = n;
+      units += n * (p1 - p0 + 1);
+      maxdepth = std::max(maxdepth, p1 - p0 + 1);
+    };
+    if (done[k + 1] <= k) add(k + 1, row0, done[k + 1], k);
+    done[k + 1] = k + 1;
+    for (int J = k + 2; J < nblk; ++J) {
+      const int pend = k + 1 - done[J];
+      if (pend <= 0) continue;
+      const bool mand = (J == k + 2);
+      if (!mand && (units >= budget || jb.njobs >= UPD_MAXJOBS)) break;
+      const int take = mand ? pend : std::min(pend, cap);
+      add(J, J * OB, done[J], done[J] + take - 1);
+      done[J] += take;
+    }
+    // deepest jobs first: their tiles take longest
+    int order[UPD_MAXJOBS];
+    for (int q = 0; q < jb.njobs; ++q) order[q] = q;
+    std::stable_sort(order, order + jb.njobs, [&](int a, int b) { return jb.KB[a] > jb.KB[b]; });
+    UpdJobs &js = pl.launch[k];
+    js.njobs = jb.njobs;
+    js.tile_begin[0] = 0;
+    for (int q = 0; q < jb.njobs; ++q) {
+      const int o = order[q];
+      js.col0[q] = jb.col0[o];
+      js.rowstart[q] = jb.rowstart[o];
+      js.kc0[q] = jb.kc0[o];
+      js.KB[q] = jb.KB[o];
+      js.tile_begin[q + 1] = js.tile_begin[q] + cnt[o];
+    }
+    // list-scheduling estimate of the launch: work / 255 CUs, at least the deepest tile, in
+    // whole tile times; and never less than the chain
+    const double t = std::max((double)maxdepth, std::ceil(units / 255.0));
+    pl.cost += std::max(chain_units, t);
+  }
 }
 
 hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
@@ -1255,29 +1332,33 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
       span_end(pr.trsm_spans);
     }
   };
-  // Lazy trailing update (production): column block J is only kept complete when the chain
-  // is about to need it; how far beyond that a launch goes is a budget, so that the work hides
-  // behind the chain instead of piling up in the first launches (U(0) alone took 189 us beside
-  // a 105 us chain).  done[J] = blocks [0, done[J]) have been applied to column block J.
-  // Only where the chain is the bound: when the update work per launch exceeds what hides
-  // behind a chain (large N: at N = 9800 the updates are 7 of 12 ms) every deferral ends as a
-  // few very deep tiles on a few CUs (measured 27 instead of 12 ms per step), so there every
-  // launch applies its block everywhere (`eager`, the same code with no budget).
+  // Lazy trailing update (production; plan_updates above).  PGF_LAZY_BUDGET fixes the budget
+  // (0 = no limit = the eager schedule: every launch applies its block everywhere).
   const bool lazy = fused() && !p;
   const int nblk = (N + OB - 1) / OB;
-  std::vector<int> done(nblk + 2, 0);
-  bool eager = false;
+  UpdPlan plan;
   if (lazy && nblk > 1) {
-    long long total = 0;  // tile-blocks of the whole factorisation
-    for (int J = 1; J < nblk; ++J) {
-      long long n = 0;
-      for (int c = 0; c < 2; ++c) {
-        const int j0 = J * OB + 128 * c;
-        if (j0 < N) n += (nrows - j0 + 127) / 128;
+    // cached per (N, nrows): a Newton iteration refactorises the same size many times
+    static thread_local int cN = -1, cR = -1;
+    static thread_local UpdPlan cplan;
+    if (cN != N || cR != nrows) {
+      const double chain_units = 1.9;  // ~86 us chain / ~45 us per tile-block
+      if (getenv("PGF_LAZY_BUDGET")) {
+        plan_updates(cplan, N, nrows, OB, lazy_budget(), lazy_cap(), chain_units);
+      } else {
+        UpdPlan best;
+        plan_updates(best, N, nrows, OB, 1 << 30, lazy_cap(), chain_units);  // eager
+        for (int b = 200; b <= 1400; b += 20) {
+          UpdPlan cand;
+          plan_updates(cand, N, nrows, OB, b, lazy_cap(), chain_units);
+          if (cand.cost < best.cost - 1e-9) best = std::move(cand);
+        }
+        cplan = std::move(best);
       }
-      total += n * J;
+      cN = N;
+      cR = nrows;
     }
-    eager = total / (nblk - 1) > lazy_share_max();
+    plan = cplan;
   }
   int buf = 0;
   if (N > 0) {
@@ -1296,64 +1377,7 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
     // and on request (PGF_FUSED=0) D(k + 1) and the whole of U(k) as two launches
     const int row0 = c1 + nb1;
     if (lazy) {
-      const int k = c0 / OB;
-      UpdJobs jb;
-      jb.njobs = 0;
-      int units = 0, cnt[UPD_MAXJOBS];
-      auto tiles = [&](int col0, int rowstart) {
-        int n = 0;
-        for (int c = 0; c < 2; ++c) {
-          const int j0 = col0 + 128 * c;
-          if (j0 >= N) continue;
-          const int i0 = std::max(rowstart, j0);
-          if (i0 < nrows) n += (nrows - i0 + 127) / 128;
-        }
-        return n;
-      };
-      auto add = [&](int J, int rowstart, int p0, int p1) {
-        const int n = tiles(J * OB, rowstart);
-        if (!n) return;
-        const int q = jb.njobs++;
-        jb.col0[q] = J * OB;
-        jb.rowstart[q] = rowstart;
-        jb.kc0[q] = p0 * OB;
-        jb.KB[q] = (p1 - p0 + 1) * OB;
-        cnt[q] = n;
-        units += n * (p1 - p0 + 1);
-      };
-      // needed by T(k + 1): the rows below diagonal block k + 1 (its diagonal block has had
-      // everything but block k since the previous launch, and block k from k_update_diag)
-      const int budget = eager ? (1 << 30) : lazy_budget();
-      const int cap = lazy_cap();
-      if (done[k + 1] <= k) add(k + 1, row0, done[k + 1], k);
-      done[k + 1] = k + 1;
-      // needed by k_update_diag (k + 2) / D(k + 2): column block k + 2 complete through block k;
-      // beyond that as far as the budget goes, nearest column block first, at most `cap`
-      // pending blocks per job (a job's tiles are one workgroup each, K-depth 256 per block)
-      for (int J = k + 2; J < nblk; ++J) {
-        const int pend = k + 1 - done[J];
-        if (pend <= 0) continue;
-        const bool mand = (J == k + 2);
-        if (!mand && (units >= budget || jb.njobs >= UPD_MAXJOBS)) break;
-        const int take = mand ? pend : std::min(pend, cap);
-        add(J, J * OB, done[J], done[J] + take - 1);
-        done[J] += take;
-      }
-      // deepest jobs first: their tiles take longest
-      int order[UPD_MAXJOBS];
-      for (int q = 0; q < jb.njobs; ++q) order[q] = q;
-      std::stable_sort(order, order + jb.njobs, [&](int a, int b) { return jb.KB[a] > jb.KB[b]; });
-      UpdJobs js;
-      js.njobs = jb.njobs;
-      js.tile_begin[0] = 0;
-      for (int q = 0; q < jb.njobs; ++q) {
-        const int o = order[q];
-        js.col0[q] = jb.col0[o];
-        js.rowstart[q] = jb.rowstart[o];
-        js.kc0[q] = jb.kc0[o];
-        js.KB[q] = jb.KB[o];
-        js.tile_begin[q + 1] = js.tile_begin[q] + cnt[o];
-      }
+      const UpdJobs &js = plan.launch[c0 / OB];
       const int ntiles = js.tile_begin[js.njobs];
       const int ep = ++f.help_epoch;
       if (help)
