@@ -403,11 +403,12 @@ def main():
                              "launch/latency-bound, not bandwidth-bound, at this size")
         elif pr["update_launches"] > 0 and pr["update_ms"] > 0:
             achieved = pr["update_flops"] / (pr["update_ms"] * 1e-3) / 1e12
-            traffic = (pmc_traffic("k_ldlt_update")
+            traffic = (pmc_traffic("k_update_jobs")
                        if args.workload == "dense_qp_n4096_m1024" else None)
             alg_bytes = pr["update_bytes"] / pr["update_launches"]
             roof = dict(
-                bound="mfma", kernel="k_ldlt_update", achieved=achieved,
+                bound="mfma", kernel="k_update_jobs (= update role of k_chain_update)",
+                achieved=achieved,
                 peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP64_MFMA_TFLOPS,
                 traffic=traffic,
                 algorithmic_bytes_per_launch=alg_bytes,
@@ -419,7 +420,8 @@ def main():
                 note=("per-kernel figures from an instrumented pass over the same steps in which "
                       "the factorisation's kernels run as separate launches with HIP events "
                       "around them; in the timed region the diagonal chain and the trailing "
-                      "update share one launch (k_chain_update)"),
+                      "update share one launch (k_chain_update: same tile code, same job "
+                      "table); launches follow the lazy plan, so K-depth varies per tile"),
             )
             # the STEP against the FP64-MFMA roof -- algorithmic flops of one
             # Full Newton step (factor N^3/3, solves 2 N^2, residual 2 n^2 + 4 n m) x steps/s
@@ -431,15 +433,15 @@ def main():
             roof["step_achieved"] = step_flops * (args.steps / elapsed) / 1e12
             roof["step_frac"] = roof["step_achieved"] / PEAK_FP64_MFMA_TFLOPS
             # where the step's time goes (instrumented pass, ms per step)
-            parts = {"k_diag_chain": pr["chain_ms"], "k_ldlt_update": pr["update_ms"],
+            parts = {"k_diag_chain": pr["chain_ms"], "k_update_jobs": pr["update_ms"],
                      "k_trsm_block": pr["trsm_ms"], "k_update_diag": pr["udiag_ms"]}
             dom = max(parts, key=parts.get)
             roof["time_dominant_kernel"] = dict(
                 kernel=dom, ms_per_step=parts[dom] / args.steps,
                 launches_per_step=(pr["chain_launches"] / args.steps if dom == "k_diag_chain" else None),
                 note=("the factorisation's serial pivot chain: ONE workgroup per 256-column "
-                      "block; in the production schedule it runs beside the previous block's "
-                      "k_ldlt_update inside one launch" if dom == "k_diag_chain" else None))
+                      "block; in the production schedule it runs beside trailing-update tiles "
+                      "inside one launch" if dom == "k_diag_chain" else None))
             roof["kernel_ms_per_step"] = {k: v / args.steps for k, v in parts.items()}
 
     # SURVEY.md 8d "reported separately": the back-solve step of the Simplified policy

@@ -646,8 +646,7 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
   int &s_bad = *reinterpret_cast<int *>(dI + 64);
   constexpr int NT = 64 * NW;  // NW = 16 or 8 wavefronts (8: 256 registers per lane)
   // wave: uniform per wavefront -> scalar register, role tests and tile numbers on the SALU
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l15 = lane & 15, l4 = lane >> 4;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bend = c0 + nb;
   const int ns = (nb + 63) / 64;
   // PGF_CHAIN_TIMING: phase stamps of the first sub-panel (100 MHz wall clock), thread 0
@@ -1076,11 +1075,37 @@ __global__ __launch_bounds__(64 * NW) void k_diag_chain(double *K, int64_t ldk, 
 // rowstart (or the diagonal, whichever is lower) -- from "blocks < kc0 / 256 applied" to
 // "blocks < (kc0 + KB) / 256 applied"; its 128 x 128 tiles are numbered tile_begin[q] ...
 #define UPD_MAXJOBS 96
+#define UPD_TM 128  // tile rows (x 128 columns); 64 measured the same (finer rounds, less reuse)
 struct UpdJobs {
   int njobs;
   int tile_begin[UPD_MAXJOBS + 1];
   int col0[UPD_MAXJOBS], rowstart[UPD_MAXJOBS], kc0[UPD_MAXJOBS], KB[UPD_MAXJOBS];
 };
+
+// tile t of a launch's job table.  ONE 128 x 128 tile per workgroup, 16 wavefronts as 4 x 4 with
+// 2 x 2 MFMA tiles each and two LDS stages of K-depth 32: the chain's LDS footprint allows one
+// workgroup per CU, so the 16 wavefronts share one staged panel pair.
+__device__ __forceinline__ void update_job_tile(unsigned char *smem, int t, double *K, int64_t ldk,
+                                                const double *__restrict__ dvec, int N, int nrows,
+                                                const UpdJobs &jobs) {
+  if (t >= jobs.tile_begin[jobs.njobs]) return;
+  int q = 0;
+  while (t >= jobs.tile_begin[q + 1]) ++q;
+  t -= jobs.tile_begin[q];
+  const int col0 = jobs.col0[q], rs = jobs.rowstart[q];
+  // tile column 0, then tile column 1 of the block; rows from max(rowstart, column start)
+  int j0 = col0, i0 = max(rs, j0);
+  const int n0 = (nrows - i0 + UPD_TM - 1) / UPD_TM;
+  if (t >= n0) {
+    t -= n0;
+    j0 = col0 + 128;
+    i0 = max(rs, j0);
+  }
+  i0 += UPD_TM * t;
+  const int kc0 = jobs.kc0[q];
+  update_tile<UPD_TM, 128, 32, 4, 4, 1, true>(smem, threadIdx.x, i0, j0, K, ldk, K + kc0, ldk, N,
+                                              nrows, N, kc0, jobs.KB[q], dvec + kc0);
+}
 
 template <bool HELP>
 __global__ __launch_bounds__(1024) void k_chain_update(double *K, int64_t ldk, int c0, int nb,
@@ -1105,27 +1130,15 @@ __global__ __launch_bounds__(1024) void k_chain_update(double *K, int64_t ldk, i
     helper_inverses<16>(smem, K, ldk, c0, nb, hc, epoch, flags, Linv, LinvT);
     return;
   }
-  // ONE 128 x 128 tile per workgroup, 16 wavefronts as 4 x 4 with 2 x 2 MFMA tiles each and
-  // two LDS stages: the chain's LDS footprint allows one workgroup per CU, so the 16 wavefronts
-  // share one staged panel pair instead of staging four 64 x 64 tiles' panels separately.
-  int t = b - 1 - (HELP ? (b > 8) + (b > 16) : 0);
-  if (t >= jobs.tile_begin[jobs.njobs]) return;
-  int q = 0;
-  while (t >= jobs.tile_begin[q + 1]) ++q;
-  t -= jobs.tile_begin[q];
-  const int col0 = jobs.col0[q], rs = jobs.rowstart[q];
-  // tile column 0, then tile column 1 of the block; rows from max(rowstart, column start)
-  int j0 = col0, i0 = max(rs, j0);
-  const int n0 = (nrows - i0 + 127) / 128;
-  if (t >= n0) {
-    t -= n0;
-    j0 = col0 + 128;
-    i0 = max(rs, j0);
-  }
-  i0 += 128 * t;
-  const int kc0 = jobs.kc0[q];
-  update_tile<128, 128, 32, 4, 4, 1, true>(smem, threadIdx.x, i0, j0, K, ldk, K + kc0, ldk, N, nrows,
-                                           N, kc0, jobs.KB[q], dvec + kc0);
+  update_job_tile(smem, b - 1 - (HELP ? (b > 8) + (b > 16) : 0), K, ldk, dvec, N, nrows, jobs);
+}
+
+// the update role alone (per-kernel profiling, PGF_FUSED=0): same tiles, same job table
+__global__ __launch_bounds__(1024) void k_update_jobs(double *K, int64_t ldk,
+                                                      const double *__restrict__ dvec, int N,
+                                                      int nrows, const UpdJobs jobs) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 256 * 34 * 8];
+  update_job_tile(smem, (int)blockIdx.x, K, ldk, dvec, N, nrows, jobs);
 }
 
 // ------------------------------------------------------------------ host schedule
@@ -1222,7 +1235,7 @@ static void plan_updates(UpdPlan &pl, int N, int nrows, int OB, int budget, int 
       const int j0 = col0 + 128 * c;
       if (j0 >= N) continue;
       const int i0 = std::max(rowstart, j0);
-      if (i0 < nrows) n += (nrows - i0 + 127) / 128;
+      if (i0 < nrows) n += (nrows - i0 + UPD_TM - 1) / UPD_TM;
     }
     return n;
   };
@@ -1334,21 +1347,22 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
   };
   // Lazy trailing update (production; plan_updates above).  PGF_LAZY_BUDGET fixes the budget
   // (0 = no limit = the eager schedule: every launch applies its block everywhere).
-  const bool lazy = fused() && !p;
+  const bool lazy = fused() && !p;  // one launch for chain + update; else two, same jobs
   const int nblk = (N + OB - 1) / OB;
   UpdPlan plan;
-  if (lazy && nblk > 1) {
+  if (nblk > 1) {
     // cached per (N, nrows): a Newton iteration refactorises the same size many times
     static thread_local int cN = -1, cR = -1;
     static thread_local UpdPlan cplan;
     if (cN != N || cR != nrows) {
-      const double chain_units = 1.9;  // ~86 us chain / ~45 us per tile-block
+      // ~86 us chain / time of one tile-block (64 x 128 x 256: ~21 us, 128 x 128: ~40 us)
+      const double chain_units = 86.0 / (UPD_TM == 64 ? 21.0 : 40.0);
       if (getenv("PGF_LAZY_BUDGET")) {
         plan_updates(cplan, N, nrows, OB, lazy_budget(), lazy_cap(), chain_units);
       } else {
         UpdPlan best;
         plan_updates(best, N, nrows, OB, 1 << 30, lazy_cap(), chain_units);  // eager
-        for (int b = 200; b <= 1400; b += 20) {
+        for (int b = 200 * (128 / UPD_TM); b <= 1400 * (128 / UPD_TM); b += 20 * (128 / UPD_TM)) {
           UpdPlan cand;
           plan_updates(cand, N, nrows, OB, b, lazy_cap(), chain_units);
           if (cand.cost < best.cost - 1e-9) best = std::move(cand);
@@ -1375,7 +1389,6 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
     span_end(pr.udiag_spans);
     // D(k + 1) beside trailing-update work, in one launch; while profiling (per-kernel events)
     // and on request (PGF_FUSED=0) D(k + 1) and the whole of U(k) as two launches
-    const int row0 = c1 + nb1;
     if (lazy) {
       const UpdJobs &js = plan.launch[c0 / OB];
       const int ntiles = js.tile_begin[js.njobs];
@@ -1390,7 +1403,36 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
                            js);
     } else {
       launch_d(c1);
-      if (row0 < nrows) launch_update(f, s, Wb, ldw, N, nrows, row0, c1, N, c0, OB, p, 0);
+      const UpdJobs &js = plan.launch[c0 / OB];
+      const int ntiles = js.tile_begin[js.njobs];
+      if (ntiles > 0) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (p) {
+          e0 = prof_event(p);
+          e1 = prof_event(p);
+          (void)hipEventRecord(e0, s);
+        }
+        hipLaunchKernelGGL(k_update_jobs, dim3(ntiles), dim3(1024), 0, s, f.K, f.ldk, f.dvec, N, nrows,
+                           js);
+        if (p) {
+          (void)hipEventRecord(e1, s);
+          p->update_spans.emplace_back(e0, e1);
+          // algorithmic work of the launch: entries (i, j), j <= i, of every job's region, 2 KB
+          // flops each; bytes: every such entry read and written once, the L rows of the
+          // region's rows and of its columns once per job
+          double fl = 0.0, by = 0.0;
+          for (int q = 0; q < js.njobs; ++q) {
+            const int col0 = js.col0[q], colEnd = std::min(N, col0 + OB);
+            const int rs = std::max(js.rowstart[q], col0);
+            double cnt = 0.0;
+            for (int i = rs; i < nrows; ++i) cnt += std::min(colEnd, i + 1) - col0;
+            fl += 2.0 * cnt * js.KB[q];
+            by += 16.0 * cnt + 8.0 * js.KB[q] * ((double)(nrows - rs) + (double)(colEnd - col0));
+          }
+          p->update_flops.push_back(fl);
+          p->update_bytes.push_back(by);
+        }
+      }
     }
     launch_t(c1, f.W + (size_t)(buf ^ 1) * f.wstride);
   }

@@ -103,27 +103,27 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int tid, 
   }
 
   // staging map: piece p = q*256 + tid -> row p / PPR, two doubles at column (p % PPR)*2
-  double2_t pa[PA], pb[PB], pd[SCALE ? PA : 1];
+  // (the D pair of a thread's pieces is the same for all of them: NT is a multiple of PPR)
+  static_assert(!SCALE || NT % PPR == 0, "one D pair per thread");
+  double2_t pa[PA], pb[PB], pd = (double2_t){1.0, 1.0};
   auto fetch = [&](int kk, int = 0) {
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
       const int p = q * NT + tid;
       const int row = p / PPR, kofs = (p % PPR) * 2;
-      const int gi = i0 + row;
-      double2_t va = (double2_t){0.0, 0.0};
-      if (gi < nrows) va = ld_f64x2(W + (int64_t)gi * ldw + kk + kofs, coh);
-      pa[q] = va;
-      if (SCALE) pd[q] = *reinterpret_cast<const double2_t *>(dsc + kk + kofs);
+      // rows beyond the region are clamped, not predicated: what they contribute stays in
+      // accumulator rows that are never stored, and a predicated load costs the prefetch a
+      // branch with a full s_waitcnt at its join
+      const int gi = min(i0 + row, nrows - 1);
+      pa[q] = ld_f64x2(W + (int64_t)gi * ldw + kk + kofs, coh);
     }
+    if (SCALE) pd = *reinterpret_cast<const double2_t *>(dsc + kk + (tid % PPR) * 2);
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
       const int p = q * NT + tid;
       const int row = p / PPR, kofs = (p % PPR) * 2;
-      const int gj = j0 + row;
-      double2_t vb = (double2_t){0.0, 0.0};
-      if (gj < colEnd)
-        vb = ld_f64x2(K + (int64_t)gj * ldk + kc0 + kk + kofs, coh);
-      pb[q] = vb;
+      const int gj = min(j0 + row, colEnd - 1);
+      pb[q] = ld_f64x2(K + (int64_t)gj * ldk + kc0 + kk + kofs, coh);
     }
   };
   auto stage = [&](int buf, int = 0) {
@@ -134,7 +134,7 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int tid, 
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
       const int p = q * NT + tid;
-      *reinterpret_cast<double2_t *>(&As[p / PPR][(p % PPR) * 2]) = SCALE ? -pa[q] * pd[q] : -pa[q];
+      *reinterpret_cast<double2_t *>(&As[p / PPR][(p % PPR) * 2]) = SCALE ? -pa[q] * pd : -pa[q];
     }
 #pragma unroll
     for (int q = 0; q < PB; ++q) {

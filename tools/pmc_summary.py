@@ -42,9 +42,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 3:
         rec = {}
         for k in out:
-            if "ldlt_update" not in k:
+            if "ldlt_update" not in k and "k_update_jobs" not in k:
                 continue
-            key = "kb_ldlt_update" if k.startswith("kb_") else "k_ldlt_update"
+            key = ("kb_ldlt_update" if k.startswith("kb_") else
+                   "k_update_jobs" if "k_update_jobs" in k else "k_ldlt_update")
             rec[key] = dict(out[k], kernel=k,
                             note="(2*FETCH_SIZE + WRITE_SIZE) KiB averaged over all launches; "
                                  "gfx950 FETCH_SIZE x2 correction; estimate")

@@ -1,27 +1,36 @@
-"""Summarise the last Newton step of a rocprofv3 kernel trace (per-kernel totals, timeline)."""
-import collections
+#!/usr/bin/env python3
+"""Timeline of ONE Newton step from a rocprofv3 --kernel-trace CSV: every launch between two
+consecutive k_assemble_kkt launches with its start, duration and the idle gap before it; the
+factorisation's own kernels are summarised in one line each."""
 import csv
 import glob
 import sys
 
 d = sys.argv[1]
-n_show = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-f = glob.glob(d + "/*/*kernel_trace.csv")[0]
-rows = list(csv.DictReader(open(f)))
-ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:30], r["Stream_Id"],
-             int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"])) for r in rows)
-idx = [i for i, k in enumerate(ks) if "assemble" in k[2]][-2]
-seg = ks[idx:]
-end = [i for i, k in enumerate(seg) if "step_update" in k[2]][0]
-seg = seg[: end + 1]
-t0 = seg[0][0]
-print("step span us", (seg[-1][1] - t0) / 1e3)
-tot = collections.Counter()
-cnt = collections.Counter()
-for s, e, n, q, gx, gy in seg:
-    tot[n] += e - s
-    cnt[n] += 1
-for n, v in tot.most_common(8):
-    print(f"{n:32s} {cnt[n]:4d} {v/1e3:9.1f} us")
-for s, e, n, q, gx, gy in seg[:n_show]:
-    print(f"{(s-t0)/1e3:9.1f} {(e-s)/1e3:7.1f} q={q} grid={gx}x{gy} {n}")
+f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
+rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", ""))
+        for r in csv.DictReader(open(f))]
+rows.sort()
+asm = [i for i, r in enumerate(rows) if r[2].startswith("k_assemble_kkt")]
+a, b = asm[-2], asm[-1]
+t0 = rows[a][0]
+prev_end = rows[a - 1][1] if a else t0
+fact = ("k_chain_update", "k_diag_chain", "k_trsm_block", "k_update_diag", "k_ldlt_update", "k_update_jobs")
+agg = {}
+gap_total = 0
+print(f"step = {(rows[b][0] - t0) / 1e3:.1f} us, {b - a} launches")
+for s, e, n in rows[a:b]:
+    gap = s - prev_end
+    gap_total += max(gap, 0)
+    prev_end = max(prev_end, e)
+    if n.startswith(fact):
+        k = n.split("<")[0]
+        c = agg.setdefault(k, [0, 0, 0])
+        c[0] += 1
+        c[1] += e - s
+        c[2] += max(gap, 0)
+    else:
+        print(f"{(s - t0) / 1e3:9.1f}  {(e - s) / 1e3:7.1f} us  gap {gap / 1e3:6.1f}  {n[:60]}")
+for k, (c, t, g) in agg.items():
+    print(f"   {k:20s} x{c:3d}  {t / 1e3:8.1f} us  gaps {g / 1e3:6.1f}")
+print(f"idle gaps in the step: {gap_total / 1e3:.1f} us")
