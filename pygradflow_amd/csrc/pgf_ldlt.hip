@@ -291,7 +291,11 @@ __device__ __forceinline__ void panel_body(unsigned char *smem, const int wg,
   }
 }
 
-template <int BM, int BN, int BK, int WR = 2, int WC = 2, int DB = 0>
+// bench only (EXP & 32): shader-clock and 100 MHz wall-clock stamps around one tile, to read
+// the clock the chip actually sustains under this kernel's load
+__device__ long long g_upd_clk[4];
+
+template <int BM, int BN, int BK, int WR = 2, int WC = 2, int DB = 0, int EXP = 0>
 __global__ __launch_bounds__(64 * WR * WC) void k_ldlt_update(
     double *__restrict__ K, int64_t ldk, const double *__restrict__ W, int64_t ldw, int N,
     int nrows, int row0, int col0, int colEnd, int kc0, int KB) {
@@ -302,8 +306,17 @@ __global__ __launch_bounds__(64 * WR * WC) void k_ldlt_update(
   const int i0 = row0 + by * BM;
   const int j0 = col0 + bx * BN;
   if (j0 > i0 + BM - 1) return;  // tile entirely above the diagonal
-  update_tile<BM, BN, BK, WR, WC, DB>(smem, threadIdx.x, i0, j0, K, ldk, W, ldw, N, nrows, colEnd, kc0,
-                                      KB);
+  const bool stamp = (EXP & 32) && threadIdx.x == 0 && bx == 0 && by == (int)gridDim.y / 2;
+  if (stamp) {
+    g_upd_clk[0] = clock64();
+    g_upd_clk[1] = wall_clock64();
+  }
+  update_tile<BM, BN, BK, WR, WC, DB, false, (EXP & 31)>(smem, threadIdx.x, i0, j0, K, ldk, W, ldw, N,
+                                                         nrows, colEnd, kc0, KB);
+  if (stamp) {
+    g_upd_clk[2] = clock64();
+    g_upd_clk[3] = wall_clock64();
+  }
 }
 
 template <int NB>
@@ -1556,6 +1569,22 @@ hipError_t ldlt_bench_update(int N, int KB, int variant, int reps, double *ms_ou
       case 3: PGF_LAUNCH_VARIANT(128, 128, 16, 4, 4, 1); break;
       case 9: PGF_LAUNCH_VARIANT(64, 64, 64, 2, 2, 0); break;
       case 10: PGF_LAUNCH_VARIANT(64, 64, 32, 2, 2, 0); break;
+      case 11: PGF_LAUNCH_VARIANT(128, 128, 32, 4, 4, 1); break;  // the fused update role's tile
+      // (256 x 128 and 128 x 256 tiles per 16-wavefront workgroup measured the same as 128 x 128
+      // at N >= 4864 and half of it at N = 2560)
+#define PGF_LAUNCH_EXP(X_)                                                                     \
+  hipLaunchKernelGGL((k_ldlt_update<128, 128, 32, 4, 4, 1, X_>), dim3((N + 127) / 128, (N + 127) / 128), \
+                     dim3(1024), 0, s, f.K, f.ldk, f.W, (int64_t)KB, Nt, Nt, KB, KB, Nt, 0, KBx)
+      case 21: PGF_LAUNCH_EXP(1); break;
+      case 22: PGF_LAUNCH_EXP(2); break;
+      case 23: PGF_LAUNCH_EXP(3); break;
+      case 27: PGF_LAUNCH_EXP(7); break;
+      case 28: PGF_LAUNCH_EXP(8); break;
+      case 36: PGF_LAUNCH_EXP(16); break;
+      case 43: PGF_LAUNCH_EXP(23); break;
+      case 32: PGF_LAUNCH_EXP(32); break;
+      case 75: PGF_LAUNCH_EXP(32 + 23); break;
+#undef PGF_LAUNCH_EXP
       default: PGF_LAUNCH_VARIANT(64, 64, 16, 2, 2, 0); break;
     }
 #undef PGF_LAUNCH_VARIANT
@@ -1572,6 +1601,13 @@ hipError_t ldlt_bench_update(int N, int KB, int variant, int reps, double *ms_ou
   (void)hipEventElapsedTime(&ms, e0, e1);
   *ms_out = ms / reps;
   *flops_out = (double)N * ((double)N + 1.0) * KB;
+  if (variant == 32 || variant == 75) {
+    long long c[4] = {0, 0, 0, 0};
+    (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_upd_clk), sizeof(c));
+    const double us = (double)(c[3] - c[1]) * 0.01;
+    fprintf(stderr, "one tile (middle row): %.1f us, %.0f shader cycles -> %.0f MHz\n", us,
+            (double)(c[2] - c[0]), us > 0 ? (double)(c[2] - c[0]) / us : 0.0);
+  }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   (void)hipFree(f.K);

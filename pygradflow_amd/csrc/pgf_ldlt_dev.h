@@ -60,7 +60,9 @@ __device__ __forceinline__ double fast_recip(double d) {
 // SCALE: the A operand is L itself (W points into K) and is multiplied by D (dsc[k], k from the
 // first column of the K-range) while it is staged: W = L D of ANY earlier block, not only of
 // the one whose W panel is still in its buffer (the lazy schedule of pgf_factor2.hip).
-template <int BM, int BN, int BK, int WR = 2, int WC = 2, int DB = 0, bool SCALE = false>
+// EXP (pgf_bench_update only; results are wrong by construction): 1 no global fetch after the
+// first chunk, 2 no LDS operand reads, 4 no LDS stage writes, 8 no MFMA, 16 no barriers
+template <int BM, int BN, int BK, int WR = 2, int WC = 2, int DB = 0, bool SCALE = false, int EXP = 0>
 __device__ __forceinline__ void update_tile(unsigned char *smem, const int tid, const int i0,
                                             const int j0,
                                             double *__restrict__ K, int64_t ldk,
@@ -106,7 +108,9 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int tid, 
   // (the D pair of a thread's pieces is the same for all of them: NT is a multiple of PPR)
   static_assert(!SCALE || NT % PPR == 0, "one D pair per thread");
   double2_t pa[PA], pb[PB], pd = (double2_t){1.0, 1.0};
+  bool staged_once = false;
   auto fetch = [&](int kk, int = 0) {
+    if ((EXP & 1) && kk > 0) return;
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
       const int p = q * NT + tid;
@@ -127,6 +131,8 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int tid, 
     }
   };
   auto stage = [&](int buf, int = 0) {
+    if ((EXP & 4) && buf >= 0 && staged_once) return;
+    staged_once = true;
     double(*As)[LD] = reinterpret_cast<double(*)[LD]>(smem + buf * STAGE);
     double(*Bs)[LD] = reinterpret_cast<double(*)[LD]>(smem + buf * STAGE + BM * LD * 8);
     // negate here, not at the fetch: touching the loaded value there would make the
@@ -149,14 +155,16 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int tid, 
     for (int ks = 0; ks < BK; ks += 4) {
       double a[TM], b[TN];
 #pragma unroll
-      for (int t = 0; t < TM; ++t) a[t] = As[wr * WM + t * 16 + l15][ks + l4];
+      for (int t = 0; t < TM; ++t) a[t] = (EXP & 2) ? 1e-3 * (ks + t) : As[wr * WM + t * 16 + l15][ks + l4];
 #pragma unroll
-      for (int t = 0; t < TN; ++t) b[t] = Bs[wc * WN + t * 16 + l15][ks + l4];
+      for (int t = 0; t < TN; ++t) b[t] = (EXP & 2) ? 1e-3 * (ks - t) : Bs[wc * WN + t * 16 + l15][ks + l4];
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-        for (int nj = 0; nj < TN; ++nj)
-          acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
+        for (int nj = 0; nj < TN; ++nj) {
+          if (EXP & 8) acc[mi][nj][0] += a[mi] + b[nj];
+          else acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
+        }
     }
   };
 
@@ -172,7 +180,7 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int tid, 
       if (more) fetch(kk + BK);
       compute(cur);
       if (more) stage(cur ^ 1);
-      __syncthreads();
+      if (!(EXP & 16)) __syncthreads();
       cur ^= 1;
     }
   } else {
