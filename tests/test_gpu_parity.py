@@ -637,6 +637,62 @@ def test_singular_kkt_raises_step_solver_error_and_controller_rejects(pgf):
     assert not res.accepted and res.lamb == 2.0
 
 
+def test_failed_chain_helpers_are_recovered_inside_the_call(pgf):
+    """The diagonal chain of the dense factorisation hands work to two helper workgroups of the
+    same launch.  A failed placement check or a timed-out hand-over must not
+    surface: the helpers are switched off and the factorisation -- and the step built on it --
+    is repeated inside the call that notices.  The test hook makes the next factorisation
+    report such a failure."""
+    import ctypes as C
+
+    from pygradflow_amd import _lib, problems
+
+    lib = _lib.load()
+    n, m = 700, 180  # reduced size > 512: several outer blocks, fused launches with helpers
+    mk = lambda: problems.dense_qp(n, m, seed=5, boxed_frac=0.2, box=0.05)
+    assert lib.pgf_debug_chain_helpers(1) in (0, 1)
+    ref = pgf.DeviceNewton(mk(), "Full", np.zeros(n), np.zeros(m), 1.0, 1.0)
+    dn = pgf.DeviceNewton(mk(), "Full", np.zeros(n), np.zeros(m), 1.0, 1.0)
+    try:
+        for k in range(3):
+            d0, _ = ref.step()
+            if k == 1:
+                assert lib.pgf_debug_chain_helpers(-1) == 1
+                _lib.check(lib.pgf_debug_fail_next_helper(dn._hd.h))
+            d1, _ = dn.step()
+            if k == 1:
+                assert lib.pgf_debug_chain_helpers(-1) == 0  # switched off by the recovery
+                lib.pgf_debug_chain_helpers(1)
+            x0, y0 = ref.point()
+            x1, y1 = dn.point()
+            assert np.isfinite(x1).all() and np.isfinite(y1).all()
+            # with and without helpers the deferred tiles are rounded differently (L D formed
+            # from L vs the exact W): agreement to rounding, not bitwise
+            assert G.rel_err(x1, x0) <= 1e-12 and G.rel_err(y1, y0) <= 1e-12, k
+            assert abs(d0 - d1) <= 1e-11 * max(1.0, d0)
+        # plugin path (pgf_newton_solve) and the linear-solver object (pgf_ls_create)
+        prob = mk()
+        params = pgf.Params(newton_type="Full")
+        it = pgf.Iterate(prob, params, np.zeros(n), np.zeros(m))
+        sv = pgf.HipStepSolver(prob, params, it, 1.0, 1.0)
+        sv.update_active_set(sv.func.compute_active_set(it, 1.0))
+        sv.update_derivs(it)
+        good = sv.solve(it)
+        sv.close()
+        sv = pgf.HipStepSolver(prob, params, it, 1.0, 1.0)  # nothing factorised yet
+        sv.update_active_set(sv.func.compute_active_set(it, 1.0))
+        sv.update_derivs(it)
+        _lib.check(lib.pgf_debug_fail_next_helper(sv._hd.h))
+        again = sv.solve(it)
+        assert lib.pgf_debug_chain_helpers(-1) == 0
+        assert G.rel_err(again.dx, good.dx) <= 1e-12 and G.rel_err(again.dy, good.dy) <= 1e-12
+        sv.close()
+    finally:
+        lib.pgf_debug_chain_helpers(1)
+        ref.close()
+        dn.close()
+
+
 def test_chain_failure_is_recovered_inside_the_call(pgf):
     """A chained triangular solve that fails its own checks must not surface: the
     call repeats the solve with the per-block kernels before it touches the point.  The test
