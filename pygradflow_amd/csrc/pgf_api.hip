@@ -960,11 +960,12 @@ int pgf_sparse_set_pattern(pgf_handle h, int bw, const int *pos, int nnzH, const
   HIPCHK(h, dalloc(&sp.Jb0, (size_t)m + 1));
   {
     const size_t nbk = (size_t)(N + 7) / 8 + 1;
-    HIPCHK(h, dalloc(&sp.bD, nbk * 64));
-    HIPCHK(h, dalloc(&sp.bL, nbk * 64));
-    HIPCHK(h, dalloc(&sp.bU, nbk * 64));
+    HIPCHK(h, dalloc(&sp.bD, 2 * nbk * 64));
+    HIPCHK(h, dalloc(&sp.bL, 2 * nbk * 64));
+    HIPCHK(h, dalloc(&sp.bU, 2 * nbk * 64));
     HIPCHK(h, dalloc(&sp.bDinv, nbk * 64));
-    HIPCHK(h, dalloc(&sp.bF, nbk * 8));
+    HIPCHK(h, dalloc(&sp.bF, 2 * nbk * 8));
+    sp.bstride = (int64_t)nbk;
     HIPCHK(h, dalloc(&sp.bX, nbk * 8));
     HIPCHK(h, dalloc(&sp.bneg, nbk));
   }

@@ -19,6 +19,9 @@ struct SparseDev {
   // block cyclic reduction work arrays: (N/8) blocks of 8 x 8 (D, L, U, inv D), rhs, solution
   double *bD = nullptr, *bL = nullptr, *bU = nullptr, *bDinv = nullptr, *bF = nullptr, *bX = nullptr;
   int *bneg = nullptr;                      // negative pivots met while inverting block i
+  // bD, bL, bU, bF hold TWO sets of blocks, the second bstride blocks behind the first: a launch
+  // that does two cyclic-reduction levels at once reads one set and writes the other
+  int64_t bstride = 0;
   bool values_set = false;
 };
 

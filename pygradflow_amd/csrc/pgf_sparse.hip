@@ -531,11 +531,16 @@ __device__ __forceinline__ void bcr_reduce_block(double *__restrict__ D, double 
 // of redundant work against a dependent launch of ~5 us per level) and then reduces.  The
 // left kept neighbour of an eliminated block always exists, so IT stores the inverse for the
 // back-substitution and reports the block's pivots.
-__device__ __forceinline__ void bcr_level_block(double *__restrict__ D, double *__restrict__ L,
-                                                double *__restrict__ U, double *__restrict__ F,
-                                                double *__restrict__ Dinv, int nb, int s, int i,
-                                                int lane, double *sm, int *__restrict__ flags,
-                                                int *__restrict__ negcnt) {
+// Result to (Do, Lo, Uo, Fo)[io] -- the block itself for the one-level launches, an LDS slot
+// or the other block set for the two-level ones; `report`: store the right neighbour's inverse
+// and pivot count (exactly one caller per eliminated block does).  (io0, gr): index of the
+// right neighbour in Dinv / negcnt (differs from ri when the inputs are LDS slots).
+__device__ __forceinline__ void bcr_level_block(const double *D, const double *L, const double *U,
+                                                const double *F, double *__restrict__ Dinv, int nb,
+                                                int s, int i, int lane, double *sm,
+                                                int *__restrict__ flags, int *__restrict__ negcnt,
+                                                double *Do, double *Lo, double *Uo, double *Fo, int io,
+                                                bool report, int gr) {
   double *A = sm, *B = sm + 64, *T = sm + 128, *fs = sm + 192;
   const int r = lane >> 3, c = lane & 7;
   double dv = D[(int64_t)i * 64 + lane];
@@ -566,10 +571,12 @@ __device__ __forceinline__ void bcr_level_block(double *__restrict__ D, double *
     B[lane] = D[(int64_t)ri * 64 + lane];
     int bad = 0;
     const int neg = gj_inverse8(B, lane, &bad);
-    Dinv[(int64_t)ri * 64 + lane] = B[lane];
-    if (lane == 0) {
-      if (bad) atomicOr(&flags[0], 1);
-      negcnt[ri] = neg;
+    if (report) {
+      Dinv[(int64_t)gr * 64 + lane] = B[lane];
+      if (lane == 0) {
+        if (bad) atomicOr(&flags[0], 1);
+        negcnt[gr] = neg;
+      }
     }
     const double ga = mm8(A, B, r, c);  // gamma = U_i inv(D_right)
     T[lane] = ga;
@@ -585,10 +592,10 @@ __device__ __forceinline__ void bcr_level_block(double *__restrict__ D, double *
     B[lane] = U[(int64_t)ri * 64 + lane];
     unew = -mm8(T, B, r, c);            // couples i to i + 2s
   }
-  D[(int64_t)i * 64 + lane] = dv;
-  L[(int64_t)i * 64 + lane] = lnew;
-  U[(int64_t)i * 64 + lane] = unew;
-  if (lane < 8) F[(int64_t)i * 8 + lane] = fv;
+  Do[(int64_t)io * 64 + lane] = dv;
+  Lo[(int64_t)io * 64 + lane] = lnew;
+  Uo[(int64_t)io * 64 + lane] = unew;
+  if (lane < 8) Fo[(int64_t)io * 8 + lane] = fv;
 }
 
 // x_i = inv(D_i) (f_i - L_i x_{i-s} - U_i x_{i+s});  s == 0: the last remaining block
@@ -602,8 +609,10 @@ __device__ __forceinline__ void bcr_back_block(const double *__restrict__ Dinv,
   const int le = i - s, ri = i + s;
   const bool hl = (s > 0) && le >= 0, hr = (s > 0) && ri < nb;
   if (lane < 8) {
-    xl[lane] = hl ? X[(int64_t)le * 8 + lane] : 0.0;
-    xr[lane] = hr ? X[(int64_t)ri * 8 + lane] : 0.0;
+    // L1-bypassing loads: in the two-level launch x of a neighbour comes from another
+    // wavefront of the same workgroup a moment ago
+    xl[lane] = hl ? __hip_atomic_load(X + (int64_t)le * 8 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    xr[lane] = hr ? __hip_atomic_load(X + (int64_t)ri * 8 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
   }
   if (lane < 8) {
     double acc = F[(int64_t)i * 8 + lane];
@@ -654,7 +663,51 @@ __global__ __launch_bounds__(64) void k_bcr_level(double *__restrict__ D, double
   __shared__ double sm[BCR_SCRATCH];
   const int i = blockIdx.x * 2 * s;
   if (i >= nb) return;
-  bcr_level_block(D, L, U, F, Dinv, nb, s, i, threadIdx.x, sm, flags, negcnt);
+  bcr_level_block(D, L, U, F, Dinv, nb, s, i, threadIdx.x, sm, flags, negcnt, D, L, U, F, i, true,
+                  i + s);
+}
+
+// TWO levels (strides s and 2 s) in one launch: the workgroup of block k = 4 s j keeps k through
+// both.  Its three wavefronts reduce k - 2 s, k and k + 2 s by one level side by side (from the
+// input set into LDS slots; the outer two are also reduced by the neighbouring workgroups: a
+// level of this size is bound by its launch, not by its arithmetic), then wavefront 0 reduces k
+// by the second level from the slots.  Nothing is updated in place -- the neighbours still
+// read the input set -- so the results go to the OTHER block set: k's new blocks and, for the
+// back-substitution, the level-one blocks of k + 2 s (eliminated at the second level; k - 2 s
+// is the left neighbour's k + 2 s).  Inverses and pivot counts of the eliminated blocks
+// k + s, k + 3 s (first level) and k + 2 s (second level) are this workgroup's to report.
+__global__ __launch_bounds__(192) void k_bcr_level2(const double *__restrict__ Di,
+                                                    const double *__restrict__ Li,
+                                                    const double *__restrict__ Ui,
+                                                    const double *__restrict__ Fi,
+                                                    double *__restrict__ Do, double *__restrict__ Lo,
+                                                    double *__restrict__ Uo, double *__restrict__ Fo,
+                                                    double *__restrict__ Dinv, int nb, int s,
+                                                    int *__restrict__ flags,
+                                                    int *__restrict__ negcnt) {
+  __shared__ double sm[3][BCR_SCRATCH];
+  __shared__ double Ds[3 * 64], Ls[3 * 64], Us[3 * 64], Fs[3 * 8];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int k = (int)blockIdx.x * 4 * s;
+  if (k >= nb) return;
+  const int i = k + (w - 1) * 2 * s;  // k - 2 s, k, k + 2 s
+  if (i >= 0 && i < nb)
+    bcr_level_block(Di, Li, Ui, Fi, Dinv, nb, s, i, lane, sm[w], flags, negcnt, Ds, Ls, Us, Fs, w,
+                    /*report=*/w >= 1, i + s);
+  __syncthreads();
+  if (w == 0) {
+    // second level on the slots: slot 1 = k, its neighbours slots 0 and 2 where they exist
+    const int lo = (k - 2 * s >= 0) ? 0 : 1;
+    const int cnt = ((k + 2 * s < nb) ? 3 : 2) - lo;
+    bcr_level_block(Ds + lo * 64, Ls + lo * 64, Us + lo * 64, Fs + lo * 8, Dinv, cnt, 1, 1 - lo, lane,
+                    sm[0], flags, negcnt, Do, Lo, Uo, Fo, k, /*report=*/true, k + 2 * s);
+  } else if (w == 2 && k + 2 * s < nb) {
+    // what the back-substitution of k + 2 s needs (its inverse comes from wavefront 0)
+    const int64_t g = (int64_t)(k + 2 * s);
+    Lo[g * 64 + lane] = Ls[2 * 64 + lane];
+    Uo[g * 64 + lane] = Us[2 * 64 + lane];
+    if (lane < 8) Fo[g * 8 + lane] = Fs[2 * 8 + lane];
+  }
 }
 
 // back-substitution of the blocks eliminated at this level (i mod 2s == s)
@@ -670,6 +723,32 @@ __global__ __launch_bounds__(64) void k_bcr_back(const double *__restrict__ Dinv
   bcr_back_block(Dinv, L, U, F, X, nb, s, i, threadIdx.x, sm);
 }
 
+// Back-substitution of TWO levels in one launch (the mirror of k_bcr_level2): the workgroup of
+// block j = 2 s (mod 4 s) solves j at stride 2 s (blocks of set 2: level-one values), then its
+// two wavefronts solve j - s and j + s at stride s (set 1: the input set of that launch), which
+// only need x_j and the already known x_{j -+ 2 s}.  A workgroup whose j lies beyond the last
+// block still owns j - s.
+__global__ __launch_bounds__(128) void k_bcr_back2(const double *__restrict__ Dinv,
+                                                   const double *__restrict__ L1,
+                                                   const double *__restrict__ U1,
+                                                   const double *__restrict__ F1,
+                                                   const double *__restrict__ L2,
+                                                   const double *__restrict__ U2,
+                                                   const double *__restrict__ F2,
+                                                   double *__restrict__ X, int nb, int s) {
+  __shared__ double sm[2][BCR_SCRATCH];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j = 2 * s + (int)blockIdx.x * 4 * s;
+  if (j - s >= nb) return;
+  if (w == 0 && j < nb) {
+    bcr_back_block(Dinv, L2, U2, F2, X, nb, 2 * s, j, lane, sm[0]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // x_j has reached L2 before the barrier
+  }
+  __syncthreads();
+  const int i = j + (w == 0 ? -s : s);
+  if (i < nb) bcr_back_block(Dinv, L1, U1, F1, X, nb, s, i, lane, sm[w]);
+}
+
 // All levels from stride s0 upwards, the last block, and the matching back-substitution
 // levels in ONE workgroup: at most BCR_TAIL_BLOCKS blocks are still in play there, every level
 // was two dependent launches of a few microseconds each (launch-bound), and the whole
@@ -681,6 +760,7 @@ __global__ __launch_bounds__(64) void k_bcr_back(const double *__restrict__ Dinv
 // operation is a chain of dependent HBM round trips, one CU working through them was 3x
 // slower than the launches it replaced.)
 #define BCR_TAIL_BLOCKS 32
+#define BCR_PAIR_MAX 4096  // blocks in play up to which two levels share a launch
 __global__ __launch_bounds__(1024) void k_bcr_tail(const double *__restrict__ D,
                                                    const double *__restrict__ L,
                                                    const double *__restrict__ U,
@@ -760,31 +840,67 @@ void sp_launch_bcr_solve(hipStream_t s, const SparseDev &sp, int N, int *flags) 
   // BCR_TAIL_BLOCKS blocks left: everything in one workgroup, in LDS
   // PGF_BCR_FUSED=0: separate invert / reduce launches per level
   static const bool fused_levels = !(getenv("PGF_BCR_FUSED") && atoi(getenv("PGF_BCR_FUSED")) == 0);
+  // PGF_BCR_PAIRS=0: one level per launch throughout (two per launch where two more levels
+  // are due before the tail and the level is launch-bound: at most BCR_PAIR_MAX blocks in play)
+  static const bool pairs = !(getenv("PGF_BCR_PAIRS") && atoi(getenv("PGF_BCR_PAIRS")) == 0);
+  struct Lev {
+    int s, set;     // stride; block set holding the eliminated blocks' L, U, F
+    int pair_set2;  // >= 0: first level of a fused pair, second level's blocks are in this set
+  };
+  Lev lev[40];
+  int nlev = 0, cur = 0;  // cur: set holding the blocks in play
+  auto Dp = [&](int set) { return sp.bD + (size_t)set * sp.bstride * 64; };
+  auto Lp = [&](int set) { return sp.bL + (size_t)set * sp.bstride * 64; };
+  auto Up = [&](int set) { return sp.bU + (size_t)set * sp.bstride * 64; };
+  auto Fp = [&](int set) { return sp.bF + (size_t)set * sp.bstride * 8; };
   int st = 1;
-  for (; st < nb; st *= 2) {
+  while (st < nb) {
     const int left = (nb + st - 1) / st;  // blocks still in play before this level
     if (left <= BCR_TAIL_BLOCKS) break;
-    const int nk = (nb + 2 * st - 1) / (2 * st);       // kept: 0, 2st, ...
-    if (fused_levels) {
-      hipLaunchKernelGGL(k_bcr_level, dim3(nk), dim3(64), 0, s, sp.bD, sp.bL, sp.bU, sp.bF,
-                         sp.bDinv, nb, st, flags, sp.bneg);
+    const int left2 = (nb + 2 * st - 1) / (2 * st);
+    static const int pair_max = getenv("PGF_BCR_PAIR_MAX") ? atoi(getenv("PGF_BCR_PAIR_MAX")) : BCR_PAIR_MAX;
+    if (fused_levels && pairs && left <= pair_max && left2 > BCR_TAIL_BLOCKS && 2 * st < nb) {
+      const int nk2 = (nb + 4 * st - 1) / (4 * st);  // kept through both: 0, 4st, ...
+      hipLaunchKernelGGL(k_bcr_level2, dim3(nk2), dim3(192), 0, s, Dp(cur), Lp(cur), Up(cur), Fp(cur),
+                         Dp(cur ^ 1), Lp(cur ^ 1), Up(cur ^ 1), Fp(cur ^ 1), sp.bDinv, nb, st, flags,
+                         sp.bneg);
+      lev[nlev++] = {st, cur, cur ^ 1};
+      cur ^= 1;
+      st *= 4;
       continue;
     }
-    const int ne = (nb - st + 2 * st - 1) / (2 * st);  // eliminated: st, 3st, ...
-    if (ne > 0)
-      hipLaunchKernelGGL(k_bcr_invert, dim3(ne), dim3(64), 0, s, sp.bD, sp.bDinv, nb, st, st,
-                         2 * st, flags, sp.bneg);
-    hipLaunchKernelGGL(k_bcr_reduce, dim3(nk), dim3(64), 0, s, sp.bD, sp.bL, sp.bU, sp.bF, sp.bDinv,
-                       nb, st);
+    const int nk = (nb + 2 * st - 1) / (2 * st);       // kept: 0, 2st, ...
+    if (fused_levels) {
+      hipLaunchKernelGGL(k_bcr_level, dim3(nk), dim3(64), 0, s, Dp(cur), Lp(cur), Up(cur), Fp(cur),
+                         sp.bDinv, nb, st, flags, sp.bneg);
+    } else {
+      const int ne = (nb - st + 2 * st - 1) / (2 * st);  // eliminated: st, 3st, ...
+      if (ne > 0)
+        hipLaunchKernelGGL(k_bcr_invert, dim3(ne), dim3(64), 0, s, Dp(cur), sp.bDinv, nb, st, st,
+                           2 * st, flags, sp.bneg);
+      hipLaunchKernelGGL(k_bcr_reduce, dim3(nk), dim3(64), 0, s, Dp(cur), Lp(cur), Up(cur), Fp(cur),
+                         sp.bDinv, nb, st);
+    }
+    lev[nlev++] = {st, cur, -1};
+    st *= 2;
   }
   // st: first level NOT done above (st >= nb: only the last block is left)
-  hipLaunchKernelGGL(k_bcr_tail, dim3(1), dim3(1024), 0, s, sp.bD, sp.bL, sp.bU, sp.bF, sp.bX, nb, st,
-                     flags, sp.bneg);
-  for (int bs = st / 2; bs >= 1; bs /= 2) {
+  hipLaunchKernelGGL(k_bcr_tail, dim3(1), dim3(1024), 0, s, Dp(cur), Lp(cur), Up(cur), Fp(cur), sp.bX, nb,
+                     st, flags, sp.bneg);
+  for (int q = nlev - 1; q >= 0; --q) {
+    const int bs = lev[q].s;
+    if (lev[q].pair_set2 >= 0) {
+      const int s2 = lev[q].pair_set2, s1 = lev[q].set;
+      const int nj = (nb + bs - 2 * bs + 4 * bs - 1) / (4 * bs);  // j = 2 bs + 4 bs q, j - bs < nb
+      if (nj > 0)
+        hipLaunchKernelGGL(k_bcr_back2, dim3(nj), dim3(128), 0, s, sp.bDinv, Lp(s1), Up(s1), Fp(s1),
+                           Lp(s2), Up(s2), Fp(s2), sp.bX, nb, bs);
+      continue;
+    }
     const int ne = (nb - bs + 2 * bs - 1) / (2 * bs);
     if (ne > 0)
-      hipLaunchKernelGGL(k_bcr_back, dim3(ne), dim3(64), 0, s, sp.bDinv, sp.bL, sp.bU, sp.bF, sp.bX,
-                         nb, bs, bs, 2 * bs);
+      hipLaunchKernelGGL(k_bcr_back, dim3(ne), dim3(64), 0, s, sp.bDinv, Lp(lev[q].set), Up(lev[q].set),
+                         Fp(lev[q].set), sp.bX, nb, bs, bs, 2 * bs);
   }
   hipLaunchKernelGGL(k_bcr_scatter, g1(N), dim3(256), 0, s, sp.bX, sp.brhs, N);
 }
