@@ -21,6 +21,7 @@
 // A zero or non-finite pivot sets flags[0] -> PGF_SINGULAR -> LinearSolverError, like the
 // RuntimeError of splu (lu_solver.py:13-17).
 #include "pgf_internal.h"
+#include "pgf_ldlt_dev.h"
 
 #include <algorithm>
 #include <cmath>
@@ -90,29 +91,32 @@ __global__ __launch_bounds__(1024) void k_lu_panel(double *A, int64_t ld, int N,
   }
 }
 
-// U12 = L11^-1 A12: lane <-> column of A12, the panel's unit-lower L11 broadcast from LDS
+// U12 = L11^-1 A12: lane <-> column of A12.  The panel's unit-lower L11 is wavefront-uniform
+// data: lane r < 32 of every wavefront holds ROW r of it in registers and the multipliers are
+// broadcast with v_readlane (scalar operands of the FMAs).  Read as LDS broadcasts the 496
+// entries were all hoisted to the top of the kernel -- ~1000 registers, 550 of them spilled
+// to scratch -- whatever scheduling barriers or volatile qualifiers stood in between.
+// A narrower last panel is padded with zeros.
 __global__ __launch_bounds__(256) void k_lu_trsm(double *A, int64_t ld, int N, int c0, int pb) {
-  __shared__ double L11[LU_PB][LU_PB + 1];
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < pb * pb; idx += 256) {
-    const int i = idx / pb, k = idx % pb;
-    L11[i][k] = A[(int64_t)(c0 + i) * ld + c0 + k];
-  }
-  __syncthreads();
+  const int tid = threadIdx.x, r = tid & 31;
+  double lrow[LU_PB];
+#pragma unroll
+  for (int k = 0; k < LU_PB; ++k)
+    lrow[k] = (r < pb && k < pb && k < r) ? A[(int64_t)(c0 + r) * ld + c0 + k] : 0.0;
   const int j = c0 + pb + blockIdx.x * 256 + tid;
-  if (j >= N) return;
+  const bool live = j < N;  // (no early return: every lane serves v_readlane)
   double x[LU_PB];
 #pragma unroll
-  for (int k = 0; k < LU_PB; ++k) x[k] = (k < pb) ? A[(int64_t)(c0 + k) * ld + j] : 0.0;
+  for (int k = 0; k < LU_PB; ++k) x[k] = (live && k < pb) ? A[(int64_t)(c0 + k) * ld + j] : 0.0;
 #pragma unroll
   for (int k = 0; k < LU_PB; ++k) {
 #pragma unroll
-    for (int i = k + 1; i < LU_PB; ++i)
-      if (i < pb) x[i] = fma(-L11[i][k], x[k], x[i]);
+    for (int i = k + 1; i < LU_PB; ++i) x[i] = fma(-lane_bcast(lrow[k], i), x[k], x[i]);  // L11[i][k]
+    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int k = 0; k < LU_PB; ++k)
-    if (k < pb) A[(int64_t)(c0 + k) * ld + j] = x[k];
+    if (live && k < pb) A[(int64_t)(c0 + k) * ld + j] = x[k];
 }
 
 // A22 -= L21 U12 over rows / columns [c1, N), K-depth pb <= 32 (L21 = columns [c0, c0 + pb)
