@@ -91,6 +91,8 @@ struct DenseLu {
   int *piv = nullptr;      // row interchanged with row i at step i (LAPACK convention)
   int *perm = nullptr;     // the interchanges as one permutation: (P b)[i] = b[perm[i]]
   double *work = nullptr;  // N
+  double *PT = nullptr;    // the current panel, column-major (32 x ldp): pivot search and rank-1
+  int64_t ldp = 0;         // updates run along rows, coalesced
   int *flags = nullptr;    // [0] zero / non-finite pivot
   hipStream_t stream = nullptr;
   bool factored = false;

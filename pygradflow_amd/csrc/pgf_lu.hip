@@ -9,8 +9,10 @@
 // formulations (HipLinearSolver(symmetric=False)); it is not on the headline path (the
 // symmetric reduced KKT system goes through the LDL^T kernels) and is written for
 // robustness first: classical right-looking blocked LU, panel width 32,
-//   k_lu_panel    ONE workgroup: per column pivot search (max |a|, smallest row on ties),
-//                 swap of the two full rows, scaling, rank-1 update inside the panel
+//   k_lu_panel    ONE workgroup on a column-major copy of the panel (k_lu_panel_load / _store):
+//                 per column pivot search (max |a|, smallest row on ties), interchange inside
+//                 the panel, scaling, rank-1 update; k_lu_swap_rows applies the panel's
+//                 interchanges to the rest of the rows afterwards
 //   k_lu_trsm     U12 = L11^-1 A12, one lane per column
 //   k_lu_update   A22 -= L21 U12, 64 x 64 tiles, register-blocked fp64 FMAs (on gfx950 the
 //                 vector fp64 FMA rate equals the MFMA rate; at K-depth 32 the update is
@@ -29,65 +31,118 @@
 
 #define LU_PB 32
 
-__global__ __launch_bounds__(1024) void k_lu_panel(double *A, int64_t ld, int N, int c0, int pb,
-                                                   int *__restrict__ piv, int *__restrict__ flags) {
-  __shared__ double sval[1024];
-  __shared__ int sidx[1024];
+// The panel rows [c0, N) x columns [c0, c0 + pb) as a column-major copy PT[j][r] (and back):
+// in A a column is strided by the row length, one cache line per entry -- the pivot search and
+// the rank-1 updates of a 32-column panel took 1.85 ms at N = 5120 (95 % of the factorisation).
+__global__ __launch_bounds__(256) void k_lu_panel_load(const double *__restrict__ A, int64_t ld,
+                                                       int N, int c0, int pb,
+                                                       double *__restrict__ PT, int64_t ldp) {
+  const int r = c0 + blockIdx.x * 256 + threadIdx.x;
+  if (r >= N) return;
+  const double *row = A + (int64_t)r * ld + c0;
+  for (int j = 0; j < pb; ++j) PT[(int64_t)j * ldp + r] = row[j];
+}
+__global__ __launch_bounds__(256) void k_lu_panel_store(double *__restrict__ A, int64_t ld, int N,
+                                                        int c0, int pb,
+                                                        const double *__restrict__ PT, int64_t ldp) {
+  const int r = c0 + blockIdx.x * 256 + threadIdx.x;
+  if (r >= N) return;
+  double *row = A + (int64_t)r * ld + c0;
+  for (int j = 0; j < pb; ++j) row[j] = PT[(int64_t)j * ldp + r];
+}
+
+// ONE workgroup factorises the panel in PT: per column the pivot (max |a|, smallest row on
+// ties; a NaN wins: it must be reported), the interchange of the two rows INSIDE the panel,
+// the multipliers and the rank-1 update of the panel's remaining columns.  The interchanges
+// of the rest of the two rows are k_lu_swap_rows' (after the panel, all 32 at once).
+__global__ __launch_bounds__(1024) void k_lu_panel(double *__restrict__ PT, int64_t ldp, int N, int c0,
+                                                   int pb, int *__restrict__ piv,
+                                                   int *__restrict__ flags) {
+  __shared__ double sval[16];
+  __shared__ int sidx[16];
   __shared__ double prow[LU_PB];
-  const int tid = threadIdx.x;
+  __shared__ int s_p;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto better = [](double v, int vi, double w, int wi) {  // (v, vi) beats (w, wi)
+    return (v != v && w == w) || (w == w && (v > w || (v == w && vi < wi)));
+  };
   for (int j = 0; j < pb; ++j) {
     const int col = c0 + j;
-    // ---- pivot search over rows col .. N-1 of column col
+    double *cj = PT + (int64_t)j * ldp;
     double best = -1.0;
     int bi = N;
     for (int r = col + tid; r < N; r += 1024) {
-      const double v = fabs(A[(int64_t)r * ld + col]);
-      if (v > best || (v != v && best == best)) {  // a NaN wins: it must be reported
+      const double v = fabs(cj[r]);
+      if (better(v, r, best, bi)) {
         best = v;
         bi = r;
       }
     }
-    sval[tid] = best;
-    sidx[tid] = bi;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-      if (tid < o) {
-        const double v = sval[tid + o], w = sval[tid];
-        const int vi = sidx[tid + o], wi = sidx[tid];
-        const bool take = (v != v && w == w) || (w == w && (v > w || (v == w && vi < wi)));
-        if (take) {
-          sval[tid] = v;
-          sidx[tid] = vi;
-        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double v = __shfl_down(best, off);
+      const int vi = __shfl_down(bi, off);
+      if (better(v, vi, best, bi)) {
+        best = v;
+        bi = vi;
       }
-      __syncthreads();
     }
-    const int p = min(sidx[0], N - 1);
-    const double pv = sval[0];
+    if (lane == 0) {
+      sval[wave] = best;
+      sidx[wave] = bi;
+    }
+    __syncthreads();
     if (tid == 0) {
+      double v = sval[0];
+      int vi = sidx[0];
+      for (int w = 1; w < 16; ++w)
+        if (better(sval[w], sidx[w], v, vi)) {
+          v = sval[w];
+          vi = sidx[w];
+        }
+      const int p = min(vi, N - 1);
+      s_p = p;
       piv[col] = p;
-      if (!(pv > 0.0) || !(pv <= 1.79e308)) atomicOr(&flags[0], 1);
+      if (!(v > 0.0) || !(v <= 1.79e308)) atomicOr(&flags[0], 1);
     }
-    // ---- swap the two full rows (L part to the left included, as LAPACK's dgetrf does)
-    if (p != col) {
-      for (int c = tid; c < N; c += 1024) {
-        const double a = A[(int64_t)col * ld + c], b = A[(int64_t)p * ld + c];
-        A[(int64_t)col * ld + c] = b;
-        A[(int64_t)p * ld + c] = a;
+    __syncthreads();
+    const int p = s_p;
+    // interchange inside the panel, then the pivot row's entries of the columns to the right
+    if (tid < pb) {
+      double *ct = PT + (int64_t)tid * ldp;
+      const double a = ct[col], b = ct[p];
+      ct[col] = b;
+      ct[p] = a;
+      prow[tid] = b;
+    }
+    __syncthreads();
+    const double rinv = 1.0 / prow[j];
+    for (int r = col + 1 + tid; r < N; r += 1024) {
+      const double l = cj[r] * rinv;
+      cj[r] = l;
+      for (int k = j + 1; k < pb; ++k) {
+        double *ck = PT + (int64_t)k * ldp;
+        ck[r] = fma(-l, prow[k], ck[r]);
       }
     }
     __syncthreads();
-    if (tid < pb) prow[tid] = A[(int64_t)col * ld + c0 + tid];
-    __syncthreads();
-    const double d = prow[j];
-    // ---- multipliers and the rank-1 update of the panel's remaining columns
-    for (int r = col + 1 + tid; r < N; r += 1024) {
-      double *row = A + (int64_t)r * ld + c0;
-      const double l = row[j] / d;
-      row[j] = l;
-      for (int k = j + 1; k < pb; ++k) row[k] = fma(-l, prow[k], row[k]);
+  }
+}
+
+// the panel's row interchanges applied to the columns outside it (L to the left included, as
+// LAPACK's dgetrf does): thread <-> column, the pb interchanges in their order
+__global__ __launch_bounds__(256) void k_lu_swap_rows(double *__restrict__ A, int64_t ld, int N, int c0,
+                                                      int pb, const int *__restrict__ piv) {
+  int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= c0) c += pb;  // skip the panel's own columns
+  if (c >= N) return;
+  for (int j = 0; j < pb; ++j) {
+    const int r = c0 + j, p = piv[r];
+    if (p != r) {
+      const double a = A[(int64_t)r * ld + c], b = A[(int64_t)p * ld + c];
+      A[(int64_t)r * ld + c] = b;
+      A[(int64_t)p * ld + c] = a;
     }
-    __syncthreads();
   }
 }
 
@@ -247,6 +302,8 @@ hipError_t lu_alloc(DenseLu &f, int N, hipStream_t stream) {
   if ((e = hipMalloc((void **)&f.piv, rows * sizeof(int))) != hipSuccess) return e;
   if ((e = hipMalloc((void **)&f.perm, rows * sizeof(int))) != hipSuccess) return e;
   if ((e = hipMalloc((void **)&f.work, rows * sizeof(double))) != hipSuccess) return e;
+  f.ldp = ((int64_t)rows + 15) / 16 * 16 + 16;  // (+16: panel columns do not share channels)
+  if ((e = hipMalloc((void **)&f.PT, (size_t)LU_PB * f.ldp * sizeof(double))) != hipSuccess) return e;
   if ((e = hipMalloc((void **)&f.flags, 4 * sizeof(int))) != hipSuccess) return e;
   return hipSuccess;
 }
@@ -256,6 +313,7 @@ void lu_free(DenseLu &f) {
   if (f.piv) (void)hipFree(f.piv);
   if (f.perm) (void)hipFree(f.perm);
   if (f.work) (void)hipFree(f.work);
+  if (f.PT) (void)hipFree(f.PT);
   if (f.flags) (void)hipFree(f.flags);
   f = DenseLu();
 }
@@ -267,7 +325,13 @@ int lu_factor(DenseLu &f, hipError_t *err) {
   hipError_t e = hipMemsetAsync(f.flags, 0, 4 * sizeof(int), s);
   for (int c0 = 0; c0 < N && e == hipSuccess; c0 += LU_PB) {
     const int pb = std::min(LU_PB, N - c0);
-    hipLaunchKernelGGL(k_lu_panel, dim3(1), dim3(1024), 0, s, f.A, f.ld, N, c0, pb, f.piv, f.flags);
+    const int gr = (N - c0 + 255) / 256;
+    hipLaunchKernelGGL(k_lu_panel_load, dim3(gr), dim3(256), 0, s, f.A, f.ld, N, c0, pb, f.PT, f.ldp);
+    hipLaunchKernelGGL(k_lu_panel, dim3(1), dim3(1024), 0, s, f.PT, f.ldp, N, c0, pb, f.piv, f.flags);
+    hipLaunchKernelGGL(k_lu_panel_store, dim3(gr), dim3(256), 0, s, f.A, f.ld, N, c0, pb, f.PT, f.ldp);
+    if (N > pb)
+      hipLaunchKernelGGL(k_lu_swap_rows, dim3((N - pb + 255) / 256), dim3(256), 0, s, f.A, f.ld, N, c0,
+                         pb, f.piv);
     const int c1 = c0 + pb;
     if (c1 < N) {
       hipLaunchKernelGGL(k_lu_trsm, dim3((N - c1 + 255) / 256), dim3(256), 0, s, f.A, f.ld, N, c0, pb);
