@@ -14,5 +14,9 @@ python bench.py --workload sparse_ocp_n100000_m50000 --steps 100 --warmup 5 > $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kso -- python bench.py --workload sparse_ocp_n100000_m50000 --steps 20 --warmup 2 --no-cpu-baseline > /dev/null 2>&1 && cp $(ls $O/kso/*/*kernel_stats.csv | head -1) $O/sparse_ocp_kernel_stats.csv && echo kso done
 python bench.py --workload box_qp_n16384 --steps 100 --warmup 5 > $O/bench_box_qp.json 2>/dev/null && echo box done
 python bench.py --workload box_qp_dense_n16384 --steps 6 --warmup 2 > $O/bench_box_qp_dense.json 2>/dev/null && echo boxd done
+bash tools/prof_seq.sh && cp gpurun_out/ps.txt $O/fused_launches.txt && cp gpurun_out/step.txt $O/step_timeline.txt && echo seq done
+PGF_CHAIN_TIMING=1 python tools/time_dense.py 4096 1024 3 2>&1 | grep stamps | tail -1 > $O/chain_stamps.txt
+python tools/bench_update.py 0 11 43 75 > $O/update_tile_microbench.txt 2>&1 && echo ubench done
+python tools/time_lu.py 1024 2560 5120 > $O/lu_timing.txt 2>&1 && echo lu done
 rm -rf $O/ks $O/pf1 $O/pw1 $O/pm1 $O/ksb $O/kso $O/pfb $O/pwb
 ls -la $O
