@@ -1080,6 +1080,8 @@ struct UpdJobs {
   int njobs;
   int tile_begin[UPD_MAXJOBS + 1];
   int col0[UPD_MAXJOBS], rowstart[UPD_MAXJOBS], kc0[UPD_MAXJOBS], KB[UPD_MAXJOBS];
+  int ntc[UPD_MAXJOBS];  // 128-wide tile columns of the job (2 per column block; adjacent column
+                         // blocks with the same K-range share a job: large N, eager plan)
 };
 
 // tile t of a launch's job table.  ONE 128 x 128 tile per workgroup, 16 wavefronts as 4 x 4 with
@@ -1093,13 +1095,14 @@ __device__ __forceinline__ void update_job_tile(unsigned char *smem, int t, doub
   while (t >= jobs.tile_begin[q + 1]) ++q;
   t -= jobs.tile_begin[q];
   const int col0 = jobs.col0[q], rs = jobs.rowstart[q];
-  // tile column 0, then tile column 1 of the block; rows from max(rowstart, column start)
+  // tile columns in turn; rows of each from max(rowstart, column start)
   int j0 = col0, i0 = max(rs, j0);
-  const int n0 = (nrows - i0 + UPD_TM - 1) / UPD_TM;
-  if (t >= n0) {
-    t -= n0;
-    j0 = col0 + 128;
+  for (int c = 0; c < jobs.ntc[q]; ++c) {
+    j0 = col0 + 128 * c;
     i0 = max(rs, j0);
+    const int nc = (j0 < N && i0 < nrows) ? (nrows - i0 + UPD_TM - 1) / UPD_TM : 0;
+    if (t < nc) break;
+    t -= nc;
   }
   i0 += UPD_TM * t;
   const int kc0 = jobs.kc0[q];
@@ -1247,14 +1250,25 @@ static void plan_updates(UpdPlan &pl, int N, int nrows, int OB, int budget, int 
     auto add = [&](int J, int rowstart, int p0, int p1) {
       const int n = tiles(J * OB, rowstart);
       if (!n) return;
+      units += n * (p1 - p0 + 1);
+      maxdepth = std::max(maxdepth, p1 - p0 + 1);
+      // a whole column block right behind the previous job's, same K-range: one job
+      if (jb.njobs > 0 && rowstart == J * OB) {
+        const int q = jb.njobs - 1;
+        if (jb.rowstart[q] == jb.col0[q] && jb.col0[q] + 128 * jb.ntc[q] == J * OB &&
+            jb.kc0[q] == p0 * OB && jb.KB[q] == (p1 - p0 + 1) * OB) {
+          jb.ntc[q] += OB / 128;
+          cnt[q] += n;
+          return;
+        }
+      }
       const int q = jb.njobs++;
       jb.col0[q] = J * OB;
       jb.rowstart[q] = rowstart;
       jb.kc0[q] = p0 * OB;
       jb.KB[q] = (p1 - p0 + 1) * OB;
+      jb.ntc[q] = OB / 128;
       cnt[q] = n;
-      units += n * (p1 - p0 + 1);
-      maxdepth = std::max(maxdepth, p1 - p0 + 1);
     };
     if (done[k + 1] <= k) add(k + 1, row0, done[k + 1], k);
     done[k + 1] = k + 1;
@@ -1262,7 +1276,8 @@ static void plan_updates(UpdPlan &pl, int N, int nrows, int OB, int budget, int 
       const int pend = k + 1 - done[J];
       if (pend <= 0) continue;
       const bool mand = (J == k + 2);
-      if (!mand && (units >= budget || jb.njobs >= UPD_MAXJOBS)) break;
+      // (room is kept for the jobs that must run; what is skipped here stays pending)
+      if (!mand && (units >= budget || jb.njobs >= UPD_MAXJOBS - 2)) break;
       const int take = mand ? pend : std::min(pend, cap);
       add(J, J * OB, done[J], done[J] + take - 1);
       done[J] += take;
@@ -1280,6 +1295,7 @@ static void plan_updates(UpdPlan &pl, int N, int nrows, int OB, int budget, int 
       js.rowstart[q] = jb.rowstart[o];
       js.kc0[q] = jb.kc0[o];
       js.KB[q] = jb.KB[o];
+      js.ntc[q] = jb.ntc[o];
       js.tile_begin[q + 1] = js.tile_begin[q] + cnt[o];
     }
     // list-scheduling estimate of the launch: work / 255 CUs, at least the deepest tile, in
@@ -1422,7 +1438,7 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
           // region's rows and of its columns once per job
           double fl = 0.0, by = 0.0;
           for (int q = 0; q < js.njobs; ++q) {
-            const int col0 = js.col0[q], colEnd = std::min(N, col0 + OB);
+            const int col0 = js.col0[q], colEnd = std::min(N, col0 + 128 * js.ntc[q]);
             const int rs = std::max(js.rowstart[q], col0);
             double cnt = 0.0;
             for (int i = rs; i < nrows; ++i) cnt += std::min(colEnd, i + 1) - col0;
