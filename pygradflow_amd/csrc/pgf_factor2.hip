@@ -33,6 +33,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <unordered_map>
 #include <vector>
 
 #define C_LD 66    // LDS row stride of 64-column tiles: conflict-free MFMA fragment reads
@@ -1376,14 +1377,29 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
       if (getenv("PGF_LAZY_BUDGET")) {
         plan_updates(cplan, N, nrows, OB, lazy_budget(), lazy_cap(), chain_units);
       } else {
-        UpdPlan best;
-        plan_updates(best, N, nrows, OB, 1 << 30, lazy_cap(), chain_units);  // eager
-        for (int b = 200 * (128 / UPD_TM); b <= 1400 * (128 / UPD_TM); b += 20 * (128 / UPD_TM)) {
-          UpdPlan cand;
-          plan_updates(cand, N, nrows, OB, b, lazy_cap(), chain_units);
-          if (cand.cost < best.cost - 1e-9) best = std::move(cand);
+        // the search (60 candidate plans) once per 128-row size class: the winning budget
+        // depends on the tile counts, and the reduced size moves by a few rows from step to
+        // step when the active set churns (config 5b: a new N every step)
+        static thread_local std::unordered_map<int, int> budget_of;
+        const int key = (nrows + 127) / 128;
+        auto it = budget_of.find(key);
+        if (it == budget_of.end()) {
+          UpdPlan best;
+          int best_b = 1 << 30;
+          plan_updates(best, N, nrows, OB, best_b, lazy_cap(), chain_units);  // eager
+          for (int b = 200 * (128 / UPD_TM); b <= 1400 * (128 / UPD_TM); b += 20 * (128 / UPD_TM)) {
+            UpdPlan cand;
+            plan_updates(cand, N, nrows, OB, b, lazy_cap(), chain_units);
+            if (cand.cost < best.cost - 1e-9) {
+              best = std::move(cand);
+              best_b = b;
+            }
+          }
+          budget_of.emplace(key, best_b);
+          cplan = std::move(best);
+        } else {
+          plan_updates(cplan, N, nrows, OB, it->second, lazy_cap(), chain_units);
         }
-        cplan = std::move(best);
       }
       cN = N;
       cR = nrows;
