@@ -592,11 +592,16 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_chain(const double *__restrict
   const int b = nblk - 1 - (int)(blockIdx.x >> 3);  // last block first
   const int b0 = b * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // inverse of the diagonal block, rows [16 wave, 16 wave + 16): inv[j][lane]
-  double iv[16];
-  const double *ip = Linv + (size_t)b * 4096 + (size_t)(16 * wave) * 64 + lane;
+  // inverse of the diagonal block, rows [16 wave, 16 wave + 16): inv[j][lane] -- parked in LDS
+  // until the block's own turn.  All workers of a solve must be RESIDENT on the one XCD (32
+  // CUs): a worker that starts late walks the whole chain behind the others.  In registers the
+  // inverse took the kernel to 146 VGPRs = 3 workgroups per CU = 96 workers (N <= 6144).
+  __shared__ double ivs[64][64];
+  {
+    const double *ip = Linv + (size_t)b * 4096 + (size_t)(16 * wave) * 64 + lane;
 #pragma unroll
-  for (int t = 0; t < 16; ++t) iv[t] = ip[t * 64];
+    for (int t = 0; t < 16; ++t) ivs[16 * wave + t][lane] = ip[t * 64];
+  }
   const double zb = (wave == 0 && b0 + lane < N) ? z[b0 + lane] : 0.0;
   // column `lane` of L_ab, rows [16 wave, 16 wave + 16), for a = nblk - 1 ... b + 1
   auto fetch = [&](int a, double (&lv)[16]) {
@@ -630,7 +635,7 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_chain(const double *__restrict
   // x_i = sum_j inv[j][i] r_j  (j >= i; the stored inverse is zero above the diagonal)
   double s = 0.0;
 #pragma unroll
-  for (int t = 0; t < 16; ++t) s = fma(iv[t], rs[16 * wave + t], s);
+  for (int t = 0; t < 16; ++t) s = fma(ivs[16 * wave + t][lane], rs[16 * wave + t], s);
   part[wave][lane] = s;
   __syncthreads();
   if (wave == 0) {
@@ -659,11 +664,14 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_chain(const double *__restrict
   const int b = (int)(blockIdx.x >> 3);  // first block first
   const int b0 = b * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // LinvT[j][i] = inv[i][j]: rows j in [16 wave, 16 wave + 16), column i = lane
-  double iv[16];
-  const double *ip = LinvT + (size_t)b * 4096 + (size_t)(16 * wave) * 64 + lane;
+  // LinvT[j][i] = inv[i][j]: rows j in [16 wave, 16 wave + 16), column i = lane (parked in LDS,
+  // see k_trsv_bwd_chain)
+  __shared__ double ivs[64][64];
+  {
+    const double *ip = LinvT + (size_t)b * 4096 + (size_t)(16 * wave) * 64 + lane;
 #pragma unroll
-  for (int t = 0; t < 16; ++t) iv[t] = ip[t * 64];
+    for (int t = 0; t < 16; ++t) ivs[16 * wave + t][lane] = ip[t * 64];
+  }
   const double zb = (wave == 0 && b0 + lane < N) ? z[b0 + lane] : 0.0;
   // lane <-> ROW b0 + lane; wavefront w takes columns [16 w, 16 w + 16) of every block a: 128
   // contiguous bytes per lane (one cache line each, not coalesced across lanes), so that the
@@ -703,7 +711,7 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_chain(const double *__restrict
   // y_i = sum_j inv[i][j] r_j
   double s = 0.0;
 #pragma unroll
-  for (int t = 0; t < 16; ++t) s = fma(iv[t], rs[16 * wave + t], s);
+  for (int t = 0; t < 16; ++t) s = fma(ivs[16 * wave + t][lane], rs[16 * wave + t], s);
   part[wave][lane] = s;
   __syncthreads();
   if (wave == 0) {
