@@ -1,0 +1,37 @@
+"""Every schedule switch of the dense factorisation gives the same factors (GPU).
+
+The switches are read once per process, so each variant runs tools/check_factor.py --no-time in
+a child process: HipLinearSolver against numpy on quasi-definite matrices of awkward sizes
+(1 ... 2561), solution, inertia and |L D L' - K| checked there."""
+
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+VARIANTS = {
+    "default": {},
+    "no_helpers": {"PGF_CHAIN_HELP": "0"},
+    "chain_8_wavefronts": {"PGF_CHAIN_WAVES": "8"},
+    "unfused_launches": {"PGF_FUSED": "0"},
+    "eager_update_plan": {"PGF_LAZY_BUDGET": "0"},
+    "tight_update_budget": {"PGF_LAZY_BUDGET": "40", "PGF_LAZY_CAP": "1"},
+    "legacy_schedule": {"PGF_FACTOR": "1"},
+    "solves_per_super_block": {"PGF_TRSV_CHAIN": "0"},
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_schedule_variant_factorises_correctly(gpu_available, name):
+    if not gpu_available:
+        pytest.skip("needs a GPU")
+    env = dict(os.environ)
+    env.update(VARIANTS[name])
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "check_factor.py"), "--no-time"],
+                         env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "linear solver ok" in out.stdout
