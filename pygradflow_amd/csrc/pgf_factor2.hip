@@ -161,16 +161,14 @@ __global__ __launch_bounds__(4 * TS * TS / 16) void k_update_diag(double *K, int
 // k = 8 (q / 2) + 2 l4 + (q & 1), so that both operands come as aligned 16-byte pairs.
 // 16 rows per workgroup because the MFMA work of a workgroup runs on ONE CU's matrix pipes
 // (0.3 TFLOP/s): 64 rows took 34 us.
-__global__ __launch_bounds__(256) void k_trsm_block(double *K, int64_t ldk, double *W, int64_t ldw,
-                                                    int nrows, int c0, int nb,
-                                                    const double *__restrict__ dinv,
-                                                    const double *__restrict__ Linv) {
-  __shared__ __attribute__((aligned(16))) double Xs[4][16][C_LD];
-  __shared__ double ds[256];
+__device__ __forceinline__ void trsm_block_body(double (*Xs)[16][C_LD], double *ds, int wg, double *K,
+                                                int64_t ldk, double *W, int64_t ldw, int nrows,
+                                                int c0, int nb, const double *__restrict__ dinv,
+                                                const double *__restrict__ Linv) {
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int bend = c0 + nb;
-  const int r0 = bend + 16 * (int)blockIdx.x;
+  const int r0 = bend + 16 * wg;
   const int ns = (nb + 63) / 64;
   constexpr int DEPTH = 3;
   double2_t bq[DEPTH][8];
@@ -264,6 +262,32 @@ __global__ __launch_bounds__(256) void k_trsm_block(double *K, int64_t ldk, doub
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_trsm_block(double *K, int64_t ldk, double *W, int64_t ldw,
+                                                    int nrows, int c0, int nb,
+                                                    const double *__restrict__ dinv,
+                                                    const double *__restrict__ Linv) {
+  __shared__ __attribute__((aligned(16))) double Xs[4][16][C_LD];
+  __shared__ double ds[256];
+  trsm_block_body(Xs, ds, (int)blockIdx.x, K, ldk, W, ldw, nrows, c0, nb, dinv, Linv);
+}
+
+// batched: instance = tab[..] (its own N, known on the device), workgroup wg of `per`
+__global__ __launch_bounds__(256) void kb_trsm_block(const BInst *__restrict__ tab, int B, int per,
+                                                     int m, int wbuf, int c0) {
+  __shared__ __attribute__((aligned(16))) double Xs[4][16][C_LD];
+  __shared__ double ds[256];
+  int inst, wg;
+  if (!batch_decode(B, per, inst, wg)) return;
+  const BInst &I = tab[inst];
+  if (I.ctl[0] == 0) return;
+  const int N = I.counts[0] + m, nrows = N + 1;
+  if (c0 >= N) return;
+  const int nb = min(256, N - c0);
+  if (c0 + nb + 16 * wg >= nrows) return;
+  trsm_block_body(Xs, ds, wg, I.K, I.ldk, I.W + (int64_t)wbuf * I.wstride, 256, nrows, c0, nb, I.dinv,
+                  I.Linv);
 }
 
 // ------------------------------------------------------------------ D(k)
@@ -1143,6 +1167,28 @@ __global__ __launch_bounds__(1024) void k_update_jobs(double *K, int64_t ldk,
                                                       int nrows, const UpdJobs jobs) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 256 * 34 * 8];
   update_job_tile(smem, (int)blockIdx.x, K, ldk, dvec, N, nrows, jobs);
+}
+
+// ------------------------------------------------------------------ batched wrappers
+// The same chain and T(k) kernels with a batch dimension: instance = workgroup (chain) or
+// batch_decode (T); every instance has its own N on the device, workgroups beyond it return.
+// The chain runs WITHOUT helper workgroups here: with hundreds of instances there is one
+// chain per CU and a spinning helper could wait for a CU its own chain occupies.
+__global__ __launch_bounds__(1024) void kb_diag_chain(const BInst *__restrict__ tab, int m, int c0) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[CH_SMEM];
+  const BInst &I = tab[blockIdx.x];  // workgroup i -> XCD i % 8, as batch_decode pins it
+  if (I.ctl[0] == 0) return;
+  const int N = I.counts[0] + m;
+  if (c0 >= N) return;
+  chain_body<16, false>(smem, I.K, I.ldk, c0, min(256, N - c0), I.dvec, I.dinv, I.flags, I.Linv, I.LinvT,
+                        nullptr, nullptr, 0);
+}
+
+void ldlt_batch_launch_chain(hipStream_t s, const BInst *tab, int B, int m, int c0) {
+  hipLaunchKernelGGL(kb_diag_chain, dim3(B), dim3(1024), 0, s, tab, m, c0);
+}
+void ldlt_batch_launch_trsm(hipStream_t s, const BInst *tab, int B, int per, int m, int wbuf, int c0) {
+  hipLaunchKernelGGL(kb_trsm_block, dim3(batch_grid(B, per)), dim3(256), 0, s, tab, B, per, m, wbuf, c0);
 }
 
 // ------------------------------------------------------------------ host schedule

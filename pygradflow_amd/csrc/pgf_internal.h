@@ -181,6 +181,9 @@ void batch_launch_res_norm(hipStream_t s, const BInst *tab, int B, const BatchSc
 void batch_launch_measures(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc,
                            int nparts, double active_tol, double *red4, double *out);
 // pgf_ldlt.hip
+// batched wrappers of the look-ahead schedule's chain and T(k) kernels (pgf_factor2.hip)
+void ldlt_batch_launch_chain(hipStream_t s, const BInst *tab, int B, int m, int c0);
+void ldlt_batch_launch_trsm(hipStream_t s, const BInst *tab, int B, int per, int m, int wbuf, int c0);
 void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m, int OB,
                              PgfProfile *prof);
 void ldlt_batch_solve_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m,

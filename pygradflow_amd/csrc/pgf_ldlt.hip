@@ -737,15 +737,7 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_chain(const double *__restrict
 // rest of the id walks that class instance by instance, tile by tile), so the tiles of one
 // instance that run together share one L2 instead of every L2 seeing every instance:
 // measured on the K = 256 trailing update of 256 instances: 19.7 -> 29.9 TFLOP/s.
-__device__ __forceinline__ bool batch_decode(int B, int per, int &inst, int &t) {
-  const int id = blockIdx.x;
-  const int slot = id >> 3;
-  const int il = slot / per;
-  t = slot - il * per;
-  inst = il * 8 + (id & 7);
-  return inst < B;
-}
-static inline int batch_grid(int B, int per) { return 8 * ((B + 7) / 8) * per; }
+// (batch_decode / batch_grid: pgf_ldlt_dev.h)
 
 template <int NB>
 __global__ __launch_bounds__(256) void kb_ldlt_panel(const BInst *__restrict__ tab, int B, int per,
@@ -1479,6 +1471,39 @@ void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, i
   // PGF_BATCH_LL=0: the single-instance schedule with a batch dimension (fused panel
   // kernel + K = 64 inner updates); default: the left-looking split panel step
   const bool ll = !(getenv("PGF_BATCH_LL") && atoi(getenv("PGF_BATCH_LL")) == 0);
+  // Default (PGF_BATCH_CHAIN=0 restores the split panel steps below): per outer block ONE chain
+  // launch (the 256 x 256 diagonal block of every instance by one workgroup each,
+  // pgf_factor2.hip) and ONE T(k) launch instead of four (diagonal tile, rows below) pairs.  A
+  // small batch is bound by the number of dependent launches, not by throughput -- a rank of
+  // an 8-GPU run of BASELINE config 4 holds 32 instances: 1.98 -> 1.71 ms per batched step;
+  // 256 instances: 8.48 -> 8.17 ms.
+  static const bool chain_sched = !(getenv("PGF_BATCH_CHAIN") && atoi(getenv("PGF_BATCH_CHAIN")) == 0);
+  if (OB == 256 && chain_sched) {
+    int buf = 0;
+    for (int ob0 = 0; ob0 < Nmax; ob0 += OB, buf ^= 1) {
+      const int obEnd = std::min(ob0 + OB, Nmax);
+      ldlt_batch_launch_chain(s, tab, B, m, ob0);
+      const int below = Nmax + 1 - obEnd;
+      if (below > 0) ldlt_batch_launch_trsm(s, tab, B, (below + 15) / 16, m, buf, ob0);
+      if (obEnd < Nmax) {
+        const int tr = (Nmax + 1 - obEnd + 63) / 64, tc = (Nmax - obEnd + 63) / 64;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (p) {
+          e0 = prof_event(p);
+          e1 = prof_event(p);
+          (void)hipEventRecord(e0, s);
+        }
+        hipLaunchKernelGGL(kb_ldlt_update, dim3(batch_grid(B, tc * tr)), dim3(256), 0, s, tab, B, tc,
+                           tr, m, (int64_t)OB, buf, 0, obEnd, obEnd, 0x7fffffff, ob0, OB);
+        if (p) {
+          (void)hipEventRecord(e1, s);
+          p->update_spans.emplace_back(e0, e1);
+          p->update_flops.push_back((double)obEnd);
+        }
+      }
+    }
+    return;
+  }
   int buf = 0;
   for (int ob0 = 0; ob0 < Nmax; ob0 += OB, buf ^= 1) {
     const int obEnd = std::min(ob0 + OB, Nmax);

@@ -53,6 +53,18 @@ __device__ __forceinline__ double fast_recip(double d) {
 // the epilogue is store-only.  K-chunks of 16 go through LDS with the next chunk
 // prefetched into registers; LDS rows padded to 18 doubles (conflict-free ds_read_b64
 // for the fragment pattern, 16-byte aligned ds_write_b128).
+// Batched kernels: workgroup id -> (instance, tile).  Consecutive ids go round-robin over the 8
+// XCDs; instance i is pinned to XCD i % 8 (see the batched variants in pgf_ldlt.hip).
+__device__ __forceinline__ bool batch_decode(int B, int per, int &inst, int &t) {
+  const int id = blockIdx.x;
+  const int slot = id >> 3;
+  const int il = slot / per;
+  t = slot - il * per;
+  inst = il * 8 + (id & 7);
+  return inst < B;
+}
+static inline int batch_grid(int B, int per) { return 8 * ((B + 7) / 8) * per; }
+
 #define UPD_BM 128
 
 // BM x BN = tile (rows x columns); BK = K-chunk staged per barrier pair; 4 wavefronts as
