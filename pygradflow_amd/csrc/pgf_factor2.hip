@@ -107,14 +107,13 @@ __device__ __forceinline__ void tile_msub(double4_t &acc, double (*As)[C_LD], do
 // workgroup per TS x TS tile of the lower triangle; TS = 32: 36 workgroups of 4 wavefronts
 // (a tile is 2 TS^2 kd flops on ONE CU's matrix pipes: 6.8 us at TS = 64, 1.7 us at 32).
 template <int TS>
-__global__ __launch_bounds__(4 * TS * TS / 16) void k_update_diag(double *K, int64_t ldk,
-                                                                  const double *W, int64_t ldw,
-                                                                  int kc0, int kd, int c1, int nb1) {
+__device__ __forceinline__ void update_diag_tile(unsigned char *smem, int t, double *K, int64_t ldk,
+                                                 const double *W, int64_t ldw, int kc0, int kd,
+                                                 int c1, int nb1) {
   constexpr int WPR = TS / 16;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TS * C_LD * 8];
   double(*As)[C_LD] = reinterpret_cast<double(*)[C_LD]>(smem);
   double(*Bs)[C_LD] = reinterpret_cast<double(*)[C_LD]>(smem + TS * C_LD * 8);
-  int I = 0, t = blockIdx.x;
+  int I = 0;
   while (t > I) {
     t -= I + 1;
     ++I;
@@ -137,6 +136,28 @@ __global__ __launch_bounds__(4 * TS * TS / 16) void k_update_diag(double *K, int
     const int i = i0 + 16 * wr + l4 + 4 * r;
     if (i < lim && j < lim && j <= i) K[(int64_t)i * ldk + j] = acc[r];
   }
+}
+
+template <int TS>
+__global__ __launch_bounds__(4 * TS * TS / 16) void k_update_diag(double *K, int64_t ldk,
+                                                                  const double *W, int64_t ldw,
+                                                                  int kc0, int kd, int c1, int nb1) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TS * C_LD * 8];
+  update_diag_tile<TS>(smem, (int)blockIdx.x, K, ldk, W, ldw, kc0, kd, c1, nb1);
+}
+
+// batched: the 36 tiles of every instance's next diagonal block (block [c1 - 256, c1) applied)
+__global__ __launch_bounds__(256) void kb_update_diag(const BInst *__restrict__ tab, int B, int m,
+                                                      int wbuf, int c1) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 32 * C_LD * 8];
+  int inst, t;
+  if (!batch_decode(B, 36, inst, t)) return;
+  const BInst &I = tab[inst];
+  if (I.ctl[0] == 0) return;
+  const int N = I.counts[0] + m;
+  if (c1 >= N) return;
+  update_diag_tile<32>(smem, t, I.K, I.ldk, I.W + (int64_t)wbuf * I.wstride, 256, c1 - 256, 256, c1,
+                       min(256, N - c1));
 }
 
 // ------------------------------------------------------------------ T(k)
@@ -1184,6 +1205,62 @@ __global__ __launch_bounds__(1024) void kb_diag_chain(const BInst *__restrict__ 
                         nullptr, nullptr, 0);
 }
 
+// chains of the outer block at c1 beside the previous block's trailing update (everything below
+// the diagonal block at c1), all instances in ONE launch: workgroups [0, Bp) are the chains
+// (Bp = B rounded up to 8, so that the tiles behind them keep the instance -> XCD pinning),
+// the rest one 128 x 128 update tile each.  Small batches only: with a chain per CU the tiles
+// would queue behind them.
+__global__ __launch_bounds__(1024) void kb_chain_update(const BInst *__restrict__ tab, int B, int Bp,
+                                                        int per, int m, int wbuf, int c1) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[CH_SMEM];
+  const int id = (int)blockIdx.x;
+  if (id < Bp) {
+    if (id >= B) return;
+    const BInst &I = tab[id];
+    if (I.ctl[0] == 0) return;
+    const int N = I.counts[0] + m;
+    if (c1 >= N) return;
+    chain_body<16, false>(smem, I.K, I.ldk, c1, min(256, N - c1), I.dvec, I.dinv, I.flags, I.Linv,
+                          I.LinvT, nullptr, nullptr, 0);
+    return;
+  }
+  int inst, t;
+  if (!batch_decode_id(id - Bp, B, per, inst, t)) return;
+  const BInst &I = tab[inst];
+  if (I.ctl[0] == 0) return;
+  const int N = I.counts[0] + m, nrows = N + 1;
+  if (c1 >= N) return;
+  const int row0 = c1 + min(256, N - c1);
+  if (row0 >= nrows) return;
+  const int tr = (nrows - row0 + 127) / 128, tc = (N - c1 + 127) / 128;
+  int by = 0;
+  while (by < tr) {
+    const int nc = min(tc, (row0 + 128 * by + 127 - c1) / 128 + 1);
+    if (t < nc) break;
+    t -= nc;
+    ++by;
+  }
+  if (by >= tr) return;
+  update_tile<128, 128, 32, 4, 4, 1>(smem, threadIdx.x, row0 + 128 * by, c1 + 128 * t, I.K, I.ldk,
+                                     I.W + (int64_t)wbuf * I.wstride, 256, N, nrows, N, c1 - 256, 256);
+}
+
+void ldlt_batch_launch_update_diag(hipStream_t s, const BInst *tab, int B, int m, int wbuf, int c1) {
+  hipLaunchKernelGGL(kb_update_diag, dim3(batch_grid(B, 36)), dim3(256), 0, s, tab, B, m, wbuf, c1);
+}
+// per: tiles of the largest possible instance (Nmax) in this launch
+void ldlt_batch_launch_chain_update(hipStream_t s, const BInst *tab, int B, int Nmax, int m, int wbuf,
+                                    int c1) {
+  const int nrows = Nmax + 1, row0 = std::min(c1 + 256, Nmax);
+  int per = 0;
+  if (row0 < nrows) {
+    const int tr = (nrows - row0 + 127) / 128, tc = (Nmax - c1 + 127) / 128;
+    for (int by = 0; by < tr; ++by) per += std::min(tc, (row0 + 128 * by + 127 - c1) / 128 + 1);
+  }
+  const int Bp = 8 * ((B + 7) / 8);
+  hipLaunchKernelGGL(kb_chain_update, dim3(Bp + (per ? batch_grid(B, per) : 0)), dim3(1024), 0, s, tab,
+                     B, Bp, std::max(per, 1), m, wbuf, c1);
+}
 void ldlt_batch_launch_chain(hipStream_t s, const BInst *tab, int B, int m, int c0) {
   hipLaunchKernelGGL(kb_diag_chain, dim3(B), dim3(1024), 0, s, tab, m, c0);
 }

@@ -183,6 +183,9 @@ void batch_launch_measures(hipStream_t s, const BInst *tab, int B, const BatchSc
 // pgf_ldlt.hip
 // batched wrappers of the look-ahead schedule's chain and T(k) kernels (pgf_factor2.hip)
 void ldlt_batch_launch_chain(hipStream_t s, const BInst *tab, int B, int m, int c0);
+void ldlt_batch_launch_update_diag(hipStream_t s, const BInst *tab, int B, int m, int wbuf, int c1);
+void ldlt_batch_launch_chain_update(hipStream_t s, const BInst *tab, int B, int Nmax, int m, int wbuf,
+                                    int c1);
 void ldlt_batch_launch_trsm(hipStream_t s, const BInst *tab, int B, int per, int m, int wbuf, int c0);
 void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m, int OB,
                              PgfProfile *prof);

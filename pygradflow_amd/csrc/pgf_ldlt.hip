@@ -1478,6 +1478,24 @@ void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, i
   // an 8-GPU run of BASELINE config 4 holds 32 instances: 1.98 -> 1.71 ms per batched step;
   // 256 instances: 8.48 -> 8.17 ms.
   static const bool chain_sched = !(getenv("PGF_BATCH_CHAIN") && atoi(getenv("PGF_BATCH_CHAIN")) == 0);
+  // small batches (PGF_BATCH_FUSED_MAX, default 64 instances): the single-instance look-ahead
+  // too -- the next block's chains run beside the previous block's bulk update in one launch
+  // (k_update_diag first), most CUs being idle during a chain launch of a few workgroups
+  static const int fused_max = getenv("PGF_BATCH_FUSED_MAX") ? atoi(getenv("PGF_BATCH_FUSED_MAX")) : 64;
+  if (OB == 256 && chain_sched && B <= fused_max && !p) {
+    int buf = 0;
+    ldlt_batch_launch_chain(s, tab, B, m, 0);
+    if (Nmax + 1 - std::min(OB, Nmax) > 0)
+      ldlt_batch_launch_trsm(s, tab, B, (Nmax + 1 - std::min(OB, Nmax) + 15) / 16, m, 0, 0);
+    for (int c0 = 0; c0 + OB < Nmax; c0 += OB, buf ^= 1) {
+      const int c1 = c0 + OB, obEnd = std::min(c1 + OB, Nmax);
+      ldlt_batch_launch_update_diag(s, tab, B, m, buf, c1);
+      ldlt_batch_launch_chain_update(s, tab, B, Nmax, m, buf, c1);
+      const int below = Nmax + 1 - obEnd;
+      if (below > 0) ldlt_batch_launch_trsm(s, tab, B, (below + 15) / 16, m, buf ^ 1, c1);
+    }
+    return;
+  }
   if (OB == 256 && chain_sched) {
     int buf = 0;
     for (int ob0 = 0; ob0 < Nmax; ob0 += OB, buf ^= 1) {

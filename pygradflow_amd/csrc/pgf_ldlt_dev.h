@@ -55,6 +55,13 @@ __device__ __forceinline__ double fast_recip(double d) {
 // for the fragment pattern, 16-byte aligned ds_write_b128).
 // Batched kernels: workgroup id -> (instance, tile).  Consecutive ids go round-robin over the 8
 // XCDs; instance i is pinned to XCD i % 8 (see the batched variants in pgf_ldlt.hip).
+__device__ __forceinline__ bool batch_decode_id(int id, int B, int per, int &inst, int &t) {
+  const int slot = id >> 3;
+  const int il = slot / per;
+  t = slot - il * per;
+  inst = il * 8 + (id & 7);
+  return inst < B;
+}
 __device__ __forceinline__ bool batch_decode(int B, int per, int &inst, int &t) {
   const int id = blockIdx.x;
   const int slot = id >> 3;

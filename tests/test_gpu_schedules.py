@@ -24,6 +24,28 @@ VARIANTS = {
 }
 
 
+BATCH_VARIANTS = {
+    "fused_lookahead": {},                          # default for small batches
+    "chain_per_block": {"PGF_BATCH_FUSED_MAX": "0"},  # what larger batches run
+    "split_panel_steps": {"PGF_BATCH_CHAIN": "0"},    # the round-1 schedule
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(BATCH_VARIANTS))
+def test_batched_schedule_variant_matches_one_by_one(gpu_available, name):
+    """tools/check_batch.py: a device batch of 11 instances with different reduced sizes against
+    the same instances driven one by one, under each batched factorisation schedule."""
+    if not gpu_available:
+        pytest.skip("needs a GPU")
+    env = dict(os.environ)
+    env.update(BATCH_VARIANTS[name])
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "check_batch.py")], env=env,
+                         cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "batch ok" in out.stdout
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(VARIANTS))
 def test_schedule_variant_factorises_correctly(gpu_available, name):
