@@ -1401,6 +1401,7 @@ int pgf_batch_create(const pgf_handle *handles, int count, pgf_batch *out) {
     t.Linv = h->fac.Linv;
     t.LinvT = h->fac.LinvT;
     t.flags = h->fac.flags;
+    t.hctl = h->fac.hctl;
     // the batch owns the device-side state of the handle from here on
     h->mask_set = false;
     h->eval_fresh = false;
@@ -1684,6 +1685,10 @@ int pgf_batch_sync(pgf_batch b, int *status, int *n_neg, double *diff) {
   bool all_ok = true;
   for (int i = 0; i < b->B; ++i) {
     const bool bad = b->h_flags[3 * i] != 0;
+    // bit 1: the instance's chain helpers failed a hand-over check (kb_step_final): the step is
+    // reported like a failed factorisation -- the controllers reject and repeat it -- and the
+    // helpers are off from here on
+    if (b->h_flags[3 * i] & 2) ldlt_chain_helpers_off();
     all_ok = all_ok && !bad;
     if (status) status[i] = bad ? PGF_SINGULAR : PGF_OK;
     if (n_neg) n_neg[i] = b->h_flags[3 * i + 1];

@@ -1195,14 +1195,26 @@ __global__ __launch_bounds__(1024) void k_update_jobs(double *K, int64_t ldk,
 // batch_decode (T); every instance has its own N on the device, workgroups beyond it return.
 // The chain runs WITHOUT helper workgroups here: with hundreds of instances there is one
 // chain per CU and a spinning helper could wait for a CU its own chain occupies.
-__global__ __launch_bounds__(1024) void kb_diag_chain(const BInst *__restrict__ tab, int m, int c0) {
+template <bool HELP>
+__global__ __launch_bounds__(1024) void kb_diag_chain(const BInst *__restrict__ tab, int B, int Bp, int m,
+                                                      int c0, int epoch) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[CH_SMEM];
-  const BInst &I = tab[blockIdx.x];  // workgroup i -> XCD i % 8, as batch_decode pins it
+  // roles: [0, Bp) chains, [Bp, 2 Bp) helpers T, [2 Bp, 3 Bp) helpers I; Bp = B rounded up to 8,
+  // so that the three workgroups of an instance land on one XCD (ids equal modulo 8)
+  const int id = (int)blockIdx.x, role = id / Bp, inst = id - role * Bp;
+  if (inst >= B) return;
+  const BInst &I = tab[inst];
   if (I.ctl[0] == 0) return;
   const int N = I.counts[0] + m;
   if (c0 >= N) return;
-  chain_body<16, false>(smem, I.K, I.ldk, c0, min(256, N - c0), I.dvec, I.dinv, I.flags, I.Linv, I.LinvT,
-                        nullptr, nullptr, 0);
+  const int nb = min(256, N - c0);
+  if (role == 0)
+    chain_body<16, HELP>(smem, I.K, I.ldk, c0, nb, I.dvec, I.dinv, I.flags, I.Linv, I.LinvT, nullptr,
+                         I.hctl, epoch);
+  else if (HELP && role == 1)
+    helper_tiles<16>(smem, I.K, I.ldk, c0, nb, I.dvec, I.hctl, epoch, I.flags);
+  else if (HELP && role == 2)
+    helper_inverses<16>(smem, I.K, I.ldk, c0, nb, I.hctl, epoch, I.flags, I.Linv, I.LinvT);
 }
 
 // chains of the outer block at c1 beside the previous block's trailing update (everything below
@@ -1210,22 +1222,31 @@ __global__ __launch_bounds__(1024) void kb_diag_chain(const BInst *__restrict__ 
 // (Bp = B rounded up to 8, so that the tiles behind them keep the instance -> XCD pinning),
 // the rest one 128 x 128 update tile each.  Small batches only: with a chain per CU the tiles
 // would queue behind them.
+template <bool HELP>
 __global__ __launch_bounds__(1024) void kb_chain_update(const BInst *__restrict__ tab, int B, int Bp,
-                                                        int per, int m, int wbuf, int c1) {
+                                                        int per, int m, int wbuf, int c1, int epoch) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[CH_SMEM];
   const int id = (int)blockIdx.x;
-  if (id < Bp) {
-    if (id >= B) return;
-    const BInst &I = tab[id];
+  constexpr int NR = HELP ? 3 : 1;  // roles of the chain: chain, helper T, helper I
+  if (id < NR * Bp) {
+    const int role = id / Bp, ci = id - role * Bp;
+    if (ci >= B) return;
+    const BInst &I = tab[ci];
     if (I.ctl[0] == 0) return;
     const int N = I.counts[0] + m;
     if (c1 >= N) return;
-    chain_body<16, false>(smem, I.K, I.ldk, c1, min(256, N - c1), I.dvec, I.dinv, I.flags, I.Linv,
-                          I.LinvT, nullptr, nullptr, 0);
+    const int nb = min(256, N - c1);
+    if (role == 0)
+      chain_body<16, HELP>(smem, I.K, I.ldk, c1, nb, I.dvec, I.dinv, I.flags, I.Linv, I.LinvT, nullptr,
+                           I.hctl, epoch);
+    else if (role == 1)
+      helper_tiles<16>(smem, I.K, I.ldk, c1, nb, I.dvec, I.hctl, epoch, I.flags);
+    else
+      helper_inverses<16>(smem, I.K, I.ldk, c1, nb, I.hctl, epoch, I.flags, I.Linv, I.LinvT);
     return;
   }
   int inst, t;
-  if (!batch_decode_id(id - Bp, B, per, inst, t)) return;
+  if (!batch_decode_id(id - NR * Bp, B, per, inst, t)) return;
   const BInst &I = tab[inst];
   if (I.ctl[0] == 0) return;
   const int N = I.counts[0] + m, nrows = N + 1;
@@ -1249,8 +1270,10 @@ void ldlt_batch_launch_update_diag(hipStream_t s, const BInst *tab, int B, int m
   hipLaunchKernelGGL(kb_update_diag, dim3(batch_grid(B, 36)), dim3(256), 0, s, tab, B, m, wbuf, c1);
 }
 // per: tiles of the largest possible instance (Nmax) in this launch
+static int g_batch_epoch = 0;
+static bool chain_helpers();  // (below: PGF_CHAIN_HELP and the process-wide switch-off)
 void ldlt_batch_launch_chain_update(hipStream_t s, const BInst *tab, int B, int Nmax, int m, int wbuf,
-                                    int c1) {
+                                    int c1, bool helpers) {
   const int nrows = Nmax + 1, row0 = std::min(c1 + 256, Nmax);
   int per = 0;
   if (row0 < nrows) {
@@ -1258,11 +1281,21 @@ void ldlt_batch_launch_chain_update(hipStream_t s, const BInst *tab, int B, int 
     for (int by = 0; by < tr; ++by) per += std::min(tc, (row0 + 128 * by + 127 - c1) / 128 + 1);
   }
   const int Bp = 8 * ((B + 7) / 8);
-  hipLaunchKernelGGL(kb_chain_update, dim3(Bp + (per ? batch_grid(B, per) : 0)), dim3(1024), 0, s, tab,
-                     B, Bp, std::max(per, 1), m, wbuf, c1);
+  const int tiles = per ? batch_grid(B, per) : 0;
+  if (helpers && chain_helpers())
+    hipLaunchKernelGGL(kb_chain_update<true>, dim3(3 * Bp + tiles), dim3(1024), 0, s, tab, B, Bp,
+                       std::max(per, 1), m, wbuf, c1, ++g_batch_epoch);
+  else
+    hipLaunchKernelGGL(kb_chain_update<false>, dim3(Bp + tiles), dim3(1024), 0, s, tab, B, Bp,
+                       std::max(per, 1), m, wbuf, c1, 0);
 }
-void ldlt_batch_launch_chain(hipStream_t s, const BInst *tab, int B, int m, int c0) {
-  hipLaunchKernelGGL(kb_diag_chain, dim3(B), dim3(1024), 0, s, tab, m, c0);
+void ldlt_batch_launch_chain(hipStream_t s, const BInst *tab, int B, int m, int c0, bool helpers) {
+  const int Bp = 8 * ((B + 7) / 8);
+  if (helpers && chain_helpers())
+    hipLaunchKernelGGL(kb_diag_chain<true>, dim3(3 * Bp), dim3(1024), 0, s, tab, B, Bp, m, c0,
+                       ++g_batch_epoch);
+  else
+    hipLaunchKernelGGL(kb_diag_chain<false>, dim3(Bp), dim3(1024), 0, s, tab, B, Bp, m, c0, 0);
 }
 void ldlt_batch_launch_trsm(hipStream_t s, const BInst *tab, int B, int per, int m, int wbuf, int c0) {
   hipLaunchKernelGGL(kb_trsm_block, dim3(batch_grid(B, per)), dim3(256), 0, s, tab, B, per, m, wbuf, c0);

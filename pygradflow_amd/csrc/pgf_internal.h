@@ -125,6 +125,7 @@ struct BInst {
   int64_t wstride;
   double *dvec, *dinv, *zwork, *Linv, *LinvT;
   int *flags;
+  int *hctl;  // stamps between the instance's chain and its helper workgroups (small batches)
 };
 
 struct BatchScalars {
@@ -182,10 +183,11 @@ void batch_launch_measures(hipStream_t s, const BInst *tab, int B, const BatchSc
                            int nparts, double active_tol, double *red4, double *out);
 // pgf_ldlt.hip
 // batched wrappers of the look-ahead schedule's chain and T(k) kernels (pgf_factor2.hip)
-void ldlt_batch_launch_chain(hipStream_t s, const BInst *tab, int B, int m, int c0);
+// helpers: 3 B workgroups of 1024 threads must be resident together (small batches only)
+void ldlt_batch_launch_chain(hipStream_t s, const BInst *tab, int B, int m, int c0, bool helpers);
 void ldlt_batch_launch_update_diag(hipStream_t s, const BInst *tab, int B, int m, int wbuf, int c1);
 void ldlt_batch_launch_chain_update(hipStream_t s, const BInst *tab, int B, int Nmax, int m, int wbuf,
-                                    int c1);
+                                    int c1, bool helpers);
 void ldlt_batch_launch_trsm(hipStream_t s, const BInst *tab, int B, int per, int m, int wbuf, int c0);
 void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m, int OB,
                              PgfProfile *prof);

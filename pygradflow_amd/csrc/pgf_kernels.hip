@@ -968,10 +968,12 @@ __global__ __launch_bounds__(256) void kb_step_final(const BInst *__restrict__ t
   }
   b_final_reduce(I.red, nb, diff_out + blockIdx.z, 1);
   if (threadIdx.x == 0) {
-    flags_out[3 * blockIdx.z] = I.flags[0];
+    // bit 0: zero / non-finite pivot; bit 1: the chain's helper workgroups failed a check
+    const int bad = (I.flags[0] ? 1 : 0) | (I.flags[2] ? 2 : 0);
+    flags_out[3 * blockIdx.z] = bad;
     flags_out[3 * blockIdx.z + 1] = I.flags[1];
     flags_out[3 * blockIdx.z + 2] = I.counts[0];
-    if (I.ctl[0]) I.ctl[1] = (I.flags[0] == 0) ? 1 : 0;
+    if (I.ctl[0]) I.ctl[1] = (bad == 0) ? 1 : 0;
   }
 }
 

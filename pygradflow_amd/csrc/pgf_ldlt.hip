@@ -1483,14 +1483,18 @@ void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, i
   // (k_update_diag first), most CUs being idle during a chain launch of a few workgroups
   static const int fused_max = getenv("PGF_BATCH_FUSED_MAX") ? atoi(getenv("PGF_BATCH_FUSED_MAX")) : 64;
   if (OB == 256 && chain_sched && B <= fused_max && !p) {
+    // chain helpers (three workgroups per instance, resident together) up to 32 instances:
+    // 8: 0.96 -> 0.83 ms, 16: 1.09 -> 0.98, 32: 1.56 -> 1.52; at 64 they cost more CUs than
+    // they save chain time (2.52 -> 2.57)
+    const bool helpers = B <= 32;
     int buf = 0;
-    ldlt_batch_launch_chain(s, tab, B, m, 0);
+    ldlt_batch_launch_chain(s, tab, B, m, 0, helpers);
     if (Nmax + 1 - std::min(OB, Nmax) > 0)
       ldlt_batch_launch_trsm(s, tab, B, (Nmax + 1 - std::min(OB, Nmax) + 15) / 16, m, 0, 0);
     for (int c0 = 0; c0 + OB < Nmax; c0 += OB, buf ^= 1) {
       const int c1 = c0 + OB, obEnd = std::min(c1 + OB, Nmax);
       ldlt_batch_launch_update_diag(s, tab, B, m, buf, c1);
-      ldlt_batch_launch_chain_update(s, tab, B, Nmax, m, buf, c1);
+      ldlt_batch_launch_chain_update(s, tab, B, Nmax, m, buf, c1, helpers);
       const int below = Nmax + 1 - obEnd;
       if (below > 0) ldlt_batch_launch_trsm(s, tab, B, (below + 15) / 16, m, buf ^ 1, c1);
     }
@@ -1500,7 +1504,7 @@ void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, i
     int buf = 0;
     for (int ob0 = 0; ob0 < Nmax; ob0 += OB, buf ^= 1) {
       const int obEnd = std::min(ob0 + OB, Nmax);
-      ldlt_batch_launch_chain(s, tab, B, m, ob0);
+      ldlt_batch_launch_chain(s, tab, B, m, ob0, false);
       const int below = Nmax + 1 - obEnd;
       if (below > 0) ldlt_batch_launch_trsm(s, tab, B, (below + 15) / 16, m, buf, ob0);
       if (obEnd < Nmax) {
