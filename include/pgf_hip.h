@@ -322,6 +322,10 @@ int pgf_debug_chain_enable(int on);
  * this handle report such a failure; pgf_debug_chain_helpers(1 / 0) switches the helpers on /
  * off, (-1) only queries; returns the previous state (1 = on). */
 int pgf_debug_fail_next_helper(pgf_handle h);
+/* batched mode (chains with helpers up to 32 instances): instance 0's next factorisation reports
+ * failed helpers -- its step comes back as failed (status PGF_SINGULAR), which the controllers
+ * reject and repeat, and the helpers are switched off */
+int pgf_batch_debug_fail_next_helper(pgf_batch b);
 int pgf_debug_chain_helpers(int on);
 
 #ifdef __cplusplus

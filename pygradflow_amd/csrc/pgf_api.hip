@@ -1278,6 +1278,7 @@ struct pgf_batch_s {
   BatchScalars sc{};
   bool outer_set = false, eval_fresh = false, step_pending = false, have_mask = false;
   bool all_factored = false;
+  int inject_helper_failure = 0;  // test hook: instance 0's next factorisation reports failed helpers
   // device-resident step controller (pgf_batch_ctl_*): per-instance state, constants, and a
   // log of (lambda used, lambda next, accepted) per outer iteration and instance
   double *dctl_cs = nullptr, *dctl_cp = nullptr, *dctl_log = nullptr;
@@ -1545,12 +1546,23 @@ static void batch_enqueue_step(pgf_batch b, unsigned policy, double tau, bool ho
   // kernels of instances whose factor is still valid return at once (ctl[0] == 0); when the
   // host knows that every instance refactorises (Full) or none does, skip the other half
   const bool none_factor = !recompute && host_knows_factored;
-  if (!none_factor)
+  if (!none_factor) {
     ldlt_batch_factor_async(b->stream, b->tab, b->B, Nmax, b->m, b->OB,
                             b->prof.enabled ? &b->prof : nullptr);
+    if (b->inject_helper_failure) {
+      b->inject_helper_failure = 0;
+      ldlt_inject_helper_failure(b->stream, b->hs[0]->fac.flags);
+    }
+  }
   ldlt_batch_solve_async(b->stream, b->tab, b->B, Nmax, b->m, !force);
   batch_launch_step_update(b->stream, b->tab, b->B, b->sc, b->diff_out, b->flags_out);
   b->eval_fresh = false;
+}
+
+int pgf_batch_debug_fail_next_helper(pgf_batch b) {
+  if (!b) return PGF_INVALID;
+  b->inject_helper_failure = 1;
+  return PGF_OK;
 }
 
 int pgf_batch_step_async(pgf_batch b, unsigned policy, double tau) {

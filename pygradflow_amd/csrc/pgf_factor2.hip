@@ -1328,6 +1328,9 @@ void ldlt_chain_helpers_set(bool on) { g_help_off = !on; }
 // test hook (pgf_debug_fail_next_helper): make the factorisation just enqueued look like one
 // whose helpers failed their checks
 __global__ void k_helper_inject(int *__restrict__ flags) { atomicOr(&flags[2], 1); }
+void ldlt_inject_helper_failure(hipStream_t s, int *flags) {
+  hipLaunchKernelGGL(k_helper_inject, dim3(1), dim3(1), 0, s, flags);
+}
 
 // budget of one lazy update launch in tile-blocks (128 x 128 tile x K-depth 256; 255 CUs take
 // one each per ~47 us) and the number of pending blocks an optional job may take at once;

@@ -74,6 +74,7 @@ void ldlt_chain_set_enabled(bool on);  // test hook: undo the switch-off of a fa
 // look-ahead schedule (pgf_factor2.hip): the default; PGF_FACTOR=1 selects the round-1 one
 bool ldlt_use_lookahead();
 void ldlt_chain_helpers_off();
+void ldlt_inject_helper_failure(hipStream_t s, int *flags);  // test hook: flags[2] |= 1
 bool ldlt_chain_helpers_enabled();     // helpers requested (PGF_CHAIN_HELP) and not switched off
 void ldlt_chain_helpers_set(bool on);  // test hook: undo / force the switch-off
 hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows);

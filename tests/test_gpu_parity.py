@@ -716,6 +716,46 @@ def test_failed_chain_helpers_are_recovered_inside_the_call(pgf):
         dn.close()
 
 
+def test_batched_chain_helper_failure_fails_the_step_and_switches_helpers_off(pgf):
+    """Small device batches give every instance's chain its two helper workgroups.  A failed
+    hand-over there cannot be repaired inside the step (the batch has advanced the point), so
+    the instance's step is reported as failed -- what the controllers reject and repeat -- and
+    the helpers are switched off; the other instances and the following steps are unaffected."""
+    from pygradflow_amd import _lib, problems
+    from pygradflow_amd.batched import BatchedDeviceNewton
+
+    lib = _lib.load()
+    n, m, B = 400, 100, 4
+    make = lambda i: problems.dense_qp(n, m, seed=40 + i, boxed_frac=0.1, box=0.05)
+    lib.pgf_debug_chain_helpers(1)
+    bd = BatchedDeviceNewton(make, B, "Full", 1.0, 1.0)
+    ref = BatchedDeviceNewton(make, B, "Full", 1.0, 1.0)
+    try:
+        st, _, _ = bd.step_local()
+        st2, _, _ = ref.step_local()
+        assert not st.any() and not st2.any()
+        _lib.check(lib.pgf_batch_debug_fail_next_helper(bd._b))
+        st, _, _ = bd.step_local()
+        st2, _, _ = ref.step_local()
+        assert st[0] == _lib.PGF_SINGULAR and not st[1:].any() and not st2.any()
+        assert lib.pgf_debug_chain_helpers(-1) == 0
+        x, y = bd.points()
+        x2, y2 = ref.points()
+        assert G.rel_err(x[1:], x2[1:]) <= 1e-12 and G.rel_err(y[1:], y2[1:]) <= 1e-12
+        # without helpers from here on: the failed instance's step is taken again (its factor
+        # was fine -- only the flag was raised), everything agrees with the undisturbed batch
+        st, _, _ = bd.step_local()
+        st2, _, _ = ref.step_local()
+        assert not st.any() and not st2.any()
+        x, y = bd.points()
+        x2, y2 = ref.points()
+        assert G.rel_err(x[1:], x2[1:]) <= 1e-11
+    finally:
+        lib.pgf_debug_chain_helpers(1)
+        bd.close()
+        ref.close()
+
+
 def test_chain_failure_is_recovered_inside_the_call(pgf):
     """A chained triangular solve that fails its own checks must not surface: the
     call repeats the solve with the per-block kernels before it touches the point.  The test
