@@ -5,26 +5,34 @@
 // division of labour.  Per outer block k of 256 columns:
 //
 //   k_update_diag  (k-1 -> k)   the 256 x 256 DIAGONAL block of block k receives block k-1's
-//                               update first (10 tiles, one 16-wavefront workgroup each)
-//   k_diag_chain   D(k)         ONE workgroup of 16 wavefronts factorises that diagonal block:
-//                               four 64-column sub-panels; per sub-panel the 64 x 64 tile is
+//                               update first (36 tiles of 32 x 32, one workgroup each)
+//   k_chain_update              ONE launch with three kinds of workgroups:
+//     workgroup 0     D(k)      the chain: 16 wavefronts factorise that diagonal block -- four
+//                               64-column sub-panels; per sub-panel the 64 x 64 tile is
 //                               eliminated by wavefront 0 (lane <-> row, v_readlane broadcasts),
 //                               the block's rows below ride one 16-column step behind on
-//                               wavefronts 1-3, MFMA updates on all 16; then the inverses of
-//                               the four unit-lower diagonal tiles (the solves and k_trsm_block
-//                               multiply with them).  This is the factorisation's critical
-//                               chain of N sequential pivots -- and nothing else is.
-//   k_ldlt_update  U(k-1)       the rest of block k-1's trailing update, launched ANY-ORDER
-//                               right behind D(k): it does not wait for D(k), the two run side
-//                               by side (they touch disjoint cache lines), and the next ordinary
-//                               launch waits for both.  Look-ahead inside one queue.
+//                               wavefronts 1-3, MFMA updates on all 16.  This is the
+//                               factorisation's critical chain of N sequential pivots -- and
+//                               nothing else is.
+//     workgroups 8, 16          its helpers on the same XCD (stamps in global memory): the part
+//                               of the in-block update the chain does not need for its next
+//                               sub-panel, and the inverses of the unit-lower diagonal tiles
+//                               (the solves and k_trsm_block multiply with them)
+//     all others                one 128 x 128 tile each of trailing-update work from the lazy
+//                               plan (plan_updates): column blocks are kept complete only when
+//                               the chain is about to need them, the rest on a budget that
+//                               hides behind the chain; W = L D formed from L and D on the fly
 //   k_trsm_block   T(k)         all rows below the block: X = T inv(L_kk)^T blocked by 64
-//                               (MFMA, the tile inverses from D(k)); writes W = X = L D (the
-//                               operand of U(k)) and L = X D^-1.
+//                               (MFMA, B operands straight from L2 into registers); writes
+//                               W = X = L D (operand of k_update_diag) and L = X D^-1.
 //
-// The round-1 schedule ran 80 panel launches of 22-33 us one after the other with the bulk
-// updates between them (2.3 ms of 4.0 ms per step at N = 5120); here the serial part is
-// D(k) (~60 us per 256 columns) and for the large early blocks it hides behind U(k-1).
+// The chain and the update tiles touch disjoint cache lines and hand nothing to each other, so
+// the launch is correct whatever order its workgroups run in: look-ahead inside one queue,
+// without a second stream (hipExtAnyOrderLaunch starts kernels early but does not run them
+// side by side on this stack).  The round-1 schedule ran 80 panel launches of 22-33 us one
+// after the other with the bulk updates between them (2.3 ms of 4.0 ms per step at N = 5120);
+// here the serial part is D(k), ~86 us per 256 columns, and the update hides behind it.
+// Batched mode (kb_*): the same chain / T(k) / update-diag device code with a batch dimension.
 #include <hip/hip_ext.h>
 
 #include "pgf_internal.h"
