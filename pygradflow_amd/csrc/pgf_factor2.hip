@@ -1118,13 +1118,13 @@ __global__ __launch_bounds__(64 * NW) void k_diag_chain(double *K, int64_t ldk, 
   }
 }
 
-// ------------------------------------------------------------------ D(k + 1) beside U(k)
+// ------------------------------------------------------------------ D(k + 1) beside update tiles
 // ONE launch: workgroup 0 is the chain D(k + 1) of the next outer block (workgroups 8 and 16
-// its helpers); every other workgroup updates one 128 x 128 tile of block k's trailing update
-// U(k) below the next diagonal block (rows [row0, nrows) x columns [col0, colEnd), lower
-// triangle; update_tile of the k_ldlt_update kernel).  The two roles touch disjoint cache lines
-// and hand nothing to each other, so the launch is correct whatever order the workgroups run
-// in; dispatched first, the chain has its CU from the start.
+// its helpers); every other workgroup applies pending blocks to one 128 x 128 tile of the
+// trailing matrix below the next diagonal block, as the launch's job table says (update_tile of
+// pgf_ldlt_dev.h with the A operand scaled by D while it is staged).  The two roles touch
+// disjoint cache lines and hand nothing to each other, so the launch is correct whatever order
+// the workgroups run in; dispatched first, the chain has its CU from the start.
 // Jobs of one lazy update launch: job q brings column block [col0, col0 + 256) -- rows from
 // rowstart (or the diagonal, whichever is lower) -- from "blocks < kc0 / 256 applied" to
 // "blocks < (kc0 + KB) / 256 applied"; its 128 x 128 tiles are numbered tile_begin[q] ...
