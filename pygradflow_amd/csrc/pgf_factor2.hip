@@ -39,6 +39,7 @@
 #include "pgf_ldlt_dev.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <unordered_map>
@@ -1278,7 +1279,21 @@ void ldlt_batch_launch_update_diag(hipStream_t s, const BInst *tab, int B, int m
   hipLaunchKernelGGL(kb_update_diag, dim3(batch_grid(B, 36)), dim3(256), 0, s, tab, B, m, wbuf, c1);
 }
 // per: tiles of the largest possible instance (Nmax) in this launch
-static int g_batch_epoch = 0;
+// Epochs of the chain <-> helper stamps: ONE counter for the process, single-instance and
+// batched launches alike.  A handle's stamp words outlive the launches that wrote them (handles
+// are pooled and move in and out of batches): with a counter per handle or per mode an old
+// stamp could equal a new launch's epoch and release a helper before its chain had produced
+// anything (seen once in ~10 runs of the test suite as a wrong inertia in a batched test that
+// followed single-instance tests on the same pooled handles).
+static std::atomic<int> g_help_epoch{0};
+static int next_help_epoch() {
+  int e = ++g_help_epoch;
+  if (e <= 0 || e == 0x7fffffff) {  // wrapped: start over (2^31 launches)
+    g_help_epoch = 1;
+    e = 1;
+  }
+  return e;
+}
 static bool chain_helpers();  // (below: PGF_CHAIN_HELP and the process-wide switch-off)
 void ldlt_batch_launch_chain_update(hipStream_t s, const BInst *tab, int B, int Nmax, int m, int wbuf,
                                     int c1, bool helpers) {
@@ -1292,7 +1307,7 @@ void ldlt_batch_launch_chain_update(hipStream_t s, const BInst *tab, int B, int 
   const int tiles = per ? batch_grid(B, per) : 0;
   if (helpers && chain_helpers())
     hipLaunchKernelGGL(kb_chain_update<true>, dim3(3 * Bp + tiles), dim3(1024), 0, s, tab, B, Bp,
-                       std::max(per, 1), m, wbuf, c1, ++g_batch_epoch);
+                       std::max(per, 1), m, wbuf, c1, next_help_epoch());
   else
     hipLaunchKernelGGL(kb_chain_update<false>, dim3(Bp + tiles), dim3(1024), 0, s, tab, B, Bp,
                        std::max(per, 1), m, wbuf, c1, 0);
@@ -1301,7 +1316,7 @@ void ldlt_batch_launch_chain(hipStream_t s, const BInst *tab, int B, int m, int 
   const int Bp = 8 * ((B + 7) / 8);
   if (helpers && chain_helpers())
     hipLaunchKernelGGL(kb_diag_chain<true>, dim3(3 * Bp), dim3(1024), 0, s, tab, B, Bp, m, c0,
-                       ++g_batch_epoch);
+                       next_help_epoch());
   else
     hipLaunchKernelGGL(kb_diag_chain<false>, dim3(Bp), dim3(1024), 0, s, tab, B, Bp, m, c0, 0);
 }
@@ -1501,7 +1516,7 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
     span_begin(pr.chain_spans);
     long long *dbg = (c0 == 0) ? chain_dbg_buffer() : nullptr;
     const int nb = std::min(OB, N - c0);
-    const int ep = ++f.help_epoch;
+    const int ep = next_help_epoch();
     if (chain_waves() == 16) {
       if (help)
         hipLaunchKernelGGL((k_diag_chain<16, true>), dim3(17), dim3(1024), 0, s, f.K, f.ldk, c0, nb,
@@ -1591,7 +1606,7 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
     if (lazy) {
       const UpdJobs &js = plan.launch[c0 / OB];
       const int ntiles = js.tile_begin[js.njobs];
-      const int ep = ++f.help_epoch;
+      const int ep = next_help_epoch();
       if (help)
         hipLaunchKernelGGL(k_chain_update<true>, dim3(std::max(17, ntiles + 3)), dim3(1024), 0, s,
                            f.K, f.ldk, c1, nb1, f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, f.hctl, ep,

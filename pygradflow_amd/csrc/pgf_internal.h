@@ -43,7 +43,6 @@ struct DenseLdlt {
   int *chain = nullptr;
   int chain_stride = 0, chain_epoch = 0;
   int *hctl = nullptr;      // stamps between the diagonal chain and its helper workgroups
-  int help_epoch = 0;
   int *h_flags = nullptr;   // pinned host mirror ([3]: status word of the chained solves)
   hipStream_t stream = nullptr;
   int OB = 256;             // outer block width (K-depth of the bulk trailing update)

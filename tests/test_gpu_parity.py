@@ -716,6 +716,35 @@ def test_failed_chain_helpers_are_recovered_inside_the_call(pgf):
         dn.close()
 
 
+def test_pooled_handles_move_between_single_and_batched_use(pgf):
+    """Handles are pooled per shape and keep their chain <-> helper stamp words.  The stamps'
+    epochs must be unique across single-instance and batched launches: with one counter per
+    handle and one for the batches, a batched launch could meet a stamp of an old
+    single-instance launch carrying its own epoch and release a helper workgroup before the
+    chain had produced anything (a wrong factor, seen once in ~10 suite runs)."""
+    from pygradflow_amd import problems
+    from pygradflow_amd.batched import BatchedDeviceNewton
+
+    n, m, B = 560, 140, 4  # reduced size ~700: three outer blocks per factorisation
+    make = lambda i: problems.dense_qp(n, m, seed=70 + i, boxed_frac=0.0)
+    for rounds in range(2):
+        dn = pgf.DeviceNewton(make(0), "Full", np.zeros(n), np.zeros(m), 1.0, 1.0)
+        for _ in range(2 + rounds):
+            dn.step()
+        dn.close()  # back to the pool, stamps and all
+        bd = BatchedDeviceNewton(make, B, "Full", 1.0, 1.0)
+        ref = BatchedDeviceNewton(make, B, "Full", 1.0, 1.0, sequential=True)
+        for k in range(4):
+            st, nn, _ = bd.step_local()
+            st2, nn2, _ = ref.step_local()
+            assert not st.any() and np.array_equal(nn, nn2) and (nn == m).all(), (rounds, k)
+            x, y = bd.points()
+            x2, y2 = ref.points()
+            assert G.rel_err(x, x2) <= 1e-11 and G.rel_err(y, y2) <= 1e-11, (rounds, k)
+        bd.close()
+        ref.close()
+
+
 def test_batched_chain_helper_failure_fails_the_step_and_switches_helpers_off(pgf):
     """Small device batches give every instance's chain its two helper workgroups.  A failed
     hand-over there cannot be repaired inside the step (the batch has advanced the point), so
