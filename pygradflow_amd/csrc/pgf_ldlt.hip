@@ -546,9 +546,10 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_super(const double *__restrict
 // with the mat-vec by its inverted diagonal block.  The off-diagonal blocks are final data, so
 // they are fetched before the stamp they wait for.
 //  * Hand-over protocol: the workers are the workgroups with id % 8 == 0, which the
-//    round-robin dispatch puts on ONE XCD; solution entries and stamps are written and read
-//    with L1-bypassing (agent-scope relaxed atomic) accesses and therefore meet in that XCD's
-//    L2 -- no L2 write-back / invalidate per hand-over (with agent-scope release / acquire
+//    round-robin dispatch puts on ONE XCD; solution entries and stamps are written with plain
+//    stores (the L1 is write-through: they land in that XCD's L2 and stay there) and read with
+//    L1-bypassing (agent-scope relaxed atomic) loads, and therefore meet in that XCD's L2 -- no
+//    L2 write-back / invalidate per hand-over (with agent-scope release / acquire
 //    fences a hand-over costs 11 us instead of 2.5 us and the chain is slower than the
 //    launches it replaces).  The placement is CHECKED, not assumed: every worker reads its
 //    XCC id (s_getreg HW_REG_XCC_ID) and compares it with the other workers' through one
@@ -641,13 +642,15 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_chain(const double *__restrict
   if (wave == 0) {
     const double xv = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
     if (b0 + lane < N)
-      __hip_atomic_store(x + b0 + lane, xv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // the write-through (sc1) stores above must have left this wavefront before the stamp
-    // does: two stores of one wavefront to different L2 channels are not ordered otherwise
-    // (inline asm: the compiler may drop a builtin wait it believes redundant)
+      // plain stores (x, then the stamp): they stay in the XCD's L2, where the consumers'
+      // L1-bypassing loads find them; sc1 stores are write-through AND drop the line from L2,
+      // so every consumer load went out to the fabric (back-solve step 0.51 -> 0.49 ms)
+      x[b0 + lane] = xv;
+    // the stores above must have reached L2 before the stamp does: two stores of one
+    // wavefront to different L2 channels are not ordered otherwise (inline asm: the compiler
+    // may drop a builtin wait it believes redundant; the clobber also pins the order)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0)
-      __hip_atomic_store(stamps + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) stamps[b] = epoch;
   }
 }
 
@@ -717,13 +720,15 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_chain(const double *__restrict
   if (wave == 0) {
     const double xv = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
     if (b0 + lane < N)
-      __hip_atomic_store(x + b0 + lane, xv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // the write-through (sc1) stores above must have left this wavefront before the stamp
-    // does: two stores of one wavefront to different L2 channels are not ordered otherwise
-    // (inline asm: the compiler may drop a builtin wait it believes redundant)
+      // plain stores (x, then the stamp): they stay in the XCD's L2, where the consumers'
+      // L1-bypassing loads find them; sc1 stores are write-through AND drop the line from L2,
+      // so every consumer load went out to the fabric (back-solve step 0.51 -> 0.49 ms)
+      x[b0 + lane] = xv;
+    // the stores above must have reached L2 before the stamp does: two stores of one
+    // wavefront to different L2 channels are not ordered otherwise (inline asm: the compiler
+    // may drop a builtin wait it believes redundant; the clobber also pins the order)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0)
-      __hip_atomic_store(stamps + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) stamps[b] = epoch;
   }
 }
 
