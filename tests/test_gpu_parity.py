@@ -49,6 +49,31 @@ def test_linear_solver_random_sqd(pgf, n1, n2):
     assert sv.num_neg_eigvals() == n2
 
 
+def test_linear_solver_block_boundary_sizes(pgf):
+    """Sizes around the schedule's block boundaries (64-column sub-panels, 256-column outer
+    blocks, 128-row update tiles) and a sweep of random ones: solution, inertia and the factor
+    itself (L D L' = K) against numpy."""
+    rng0 = np.random.default_rng(2024)
+    sizes = [255, 256, 257, 319, 320, 321, 511, 512, 513, 767, 769, 1023, 1025, 1279, 1281]
+    sizes += [int(v) for v in rng0.integers(2, 2600, size=8)]
+    for N in sizes:
+        rng = np.random.default_rng(N)
+        n2 = int(rng.integers(0, max(1, N // 3)))
+        K = _sqd(rng, N - n2, n2)
+        rhs = rng.standard_normal(N)
+        sv = pgf.HipLinearSolver(K, symmetric=True)
+        try:
+            sol = sv.solve(rhs)
+            ref = np.linalg.solve(K, rhs)
+            assert G.rel_err(sol, ref) <= 1e-11, N
+            assert sv.num_neg_eigvals() == n2, N
+            F = sv.factor_matrix()
+            L = np.tril(F, -1) + np.eye(N)
+            assert np.max(np.abs((L * np.diag(F)) @ L.T - K)) <= 1e-12 * max(1.0, np.max(np.abs(K))) * N, N
+        finally:
+            sv.close()
+
+
 def test_linear_solver_singular_raises(pgf):
     K = np.zeros((4, 4))
     with pytest.raises(pgf.LinearSolverError):
