@@ -39,8 +39,10 @@ struct DenseLdlt {
   double *Linv = nullptr;   // inverse of every 64 x 64 diagonal block of L, [block][row][64]
   double *LinvT = nullptr;  // the transposes
   int *flags = nullptr;     // [0] zero-pivot flag, [1] negative pivots, [2] chain helpers failed
-  // chained solves: [0, S) backward stamps, [S, 2S) forward stamps, [2S] XCC slot, [2S+1] bad
+  // chained solves: [2S] XCC slot, [2S+1] bad (S = chain_stride = 64-row blocks of capacity);
+  // xpub: two halves of S * 64 published solution entries (sentinel = all bits set)
   int *chain = nullptr;
+  double *xpub = nullptr;
   int chain_stride = 0, chain_epoch = 0;
   int *hctl = nullptr;      // stamps between the diagonal chain and its helper workgroups
   int *h_flags = nullptr;   // pinned host mirror ([3]: status word of the chained solves)

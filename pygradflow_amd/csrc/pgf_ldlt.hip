@@ -541,37 +541,38 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_super(const double *__restrict
 // ------------------------------------------------------------------ chained triangular solves
 // One launch for a whole triangular solve instead of one per 256-row super-block (20 dependent
 // launches of ~15 us at N = 5120).  One workgroup per 64-row block; block b accumulates the
-// products with the already solved blocks AS THEY BECOME AVAILABLE -- every block publishes
-// its 64 solution entries and then an epoch stamp, consumers poll the stamp -- and finishes
-// with the mat-vec by its inverted diagonal block.  The off-diagonal blocks are final data, so
-// they are fetched before the stamp they wait for.
-//  * Hand-over protocol: the workers are the workgroups with id % 8 == 0, which the
-//    round-robin dispatch puts on ONE XCD; solution entries and stamps are written with plain
-//    stores (the L1 is write-through: they land in that XCD's L2 and stay there) and read with
-//    L1-bypassing (agent-scope relaxed atomic) loads, and therefore meet in that XCD's L2 -- no
-//    L2 write-back / invalidate per hand-over (with agent-scope release / acquire
-//    fences a hand-over costs 11 us instead of 2.5 us and the chain is slower than the
-//    launches it replaces).  The placement is CHECKED, not assumed: every worker reads its
-//    XCC id (s_getreg HW_REG_XCC_ID) and compares it with the other workers' through one
-//    atomicMax; a mismatch or a timed-out wait sets ctl[1], which the host reads at the next
-//    synchronisation: the call fails loudly and the chained solves are switched off.
+// products with the already solved blocks AS THEY BECOME AVAILABLE and finishes with the
+// mat-vec by its inverted diagonal block.  The off-diagonal blocks are final data, so they are
+// fetched before the entries they wait for.
+//  * Hand-over: the DATA is the signal.  Every solve publishes into one half of `xpub`, which
+//    holds the sentinel CHAIN_EMPTY (all bits set: a NaN no arithmetic produces) in every slot
+//    when the solve starts; a producer stores its 64 solution entries there, a consumer polls
+//    the very words it needs until none of them is the sentinel.  An aligned 8-byte store is
+//    indivisible, so a word is either the sentinel or final -- no stamp, no store-to-store
+//    ordering between data and stamp to get right (round 1's hand-over published x and then a
+//    stamp: two stores of one wavefront to different L2 channels are not ordered without a
+//    wait in between), and one L2 round trip per hand-over less.  The solve with epoch e uses
+//    half e & 1 and its workers put the sentinel back into the OTHER half (kernel boundaries
+//    order that against the next solve of the handle's stream).
+//  * Placement: the workers are the workgroups with id % 8 == 0, which the round-robin dispatch
+//    puts on ONE XCD; published entries are plain stores (the L1 is write-through: they land in
+//    that XCD's L2 and stay there) read with L1-bypassing (agent-scope relaxed atomic) loads,
+//    and therefore meet in that XCD's L2 -- no L2 write-back / invalidate per hand-over (with
+//    agent-scope release / acquire fences a hand-over costs 11 us).  The placement is CHECKED,
+//    not assumed: every worker reads its XCC id (s_getreg HW_REG_XCC_ID) and compares it with
+//    the other workers' through one atomicMax; a mismatch or a timed-out wait sets ctl[1],
+//    which the host reads at the next synchronisation: the solve is repeated with the
+//    per-super-block kernels inside the same call and the chained solves are switched off.
 //  * Termination: polls are bounded, every workgroup walks a finite loop, and a workgroup only
 //    waits for workers with a SMALLER index, which are dispatched before it.
-#define CHAIN_SPIN_LIMIT (1 << 18)  // ~0.15 s per wait; a real hand-over takes microseconds
-
-__device__ __forceinline__ void chain_wait(const int *stamp, int epoch, int *ctl) {
-  for (int it = 0; it < CHAIN_SPIN_LIMIT; ++it) {
-    if (__hip_atomic_load(stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return;
-    __builtin_amdgcn_s_sleep(1);
-  }
-  atomicOr(&ctl[1], 1);
-}
+#define CHAIN_SPIN_LIMIT (1 << 18)  // ~0.15 s per wait; a real hand-over takes about a microsecond
+#define CHAIN_EMPTY (-1LL)
 
 // all workers of a launch must sit on one XCD: ctl[0] = max over workers of (epoch << 4 | xcc)
 __device__ __forceinline__ void chain_check_xcc(int epoch, int *ctl) {
   if (threadIdx.x == 0) {
     // 27 bits of epoch: after 2^27 solves the slot stops changing and the check goes quiet
-    // (no false alarms); the stamps themselves compare full 32-bit epochs
+    // (no false alarms)
     const int ep = epoch & 0x7ffffff;
     const int mine = (ep << 4) | (int)(__builtin_amdgcn_s_getreg(6164) & 15);  // XCC_ID[3:0]
     const int old = atomicMax(&ctl[0], mine);
@@ -579,20 +580,53 @@ __device__ __forceinline__ void chain_check_xcc(int epoch, int *ctl) {
   }
 }
 
+__device__ __forceinline__ long long chain_peek(const double *p) {
+  return __hip_atomic_load(reinterpret_cast<const long long *>(p), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// lanes [0, cnt) of the wavefront hold one published entry each (`bits`, possibly still the
+// sentinel: the caller issued that load earlier); returns once none is
+__device__ __forceinline__ double chain_take(const double *p, bool mine, long long bits, int *ctl) {
+  for (int it = 0; it < CHAIN_SPIN_LIMIT; ++it) {
+    if (!__builtin_amdgcn_ballot_w64(mine && bits == CHAIN_EMPTY)) return __longlong_as_double(bits);
+    __builtin_amdgcn_s_sleep(1);
+    if (mine) bits = chain_peek(p);
+  }
+  atomicOr(&ctl[1], 1);
+  return 0.0;
+}
+
+__device__ __forceinline__ double chain_bcast(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// workers put the sentinel back into the half the NEXT solve publishes into
+__device__ __forceinline__ void chain_reset_other(double *other, int capblk, int w, int nw) {
+  if (threadIdx.x < 64)
+    for (int j = w; j < capblk; j += nw)
+      reinterpret_cast<long long *>(other)[(size_t)j * 64 + threadIdx.x] = CHAIN_EMPTY;
+}
+
 // backward: L^T x = z.  x_b = inv(L_bb)^T (z_b - sum_{a > b} L_ab^T x_a).  In place (x == z) ok.
 __global__ __launch_bounds__(256) void k_trsv_bwd_chain(const double *__restrict__ K, int64_t ldk,
                                                         const double *__restrict__ Linv,
                                                         const double *z, double *x, int N,
-                                                        int *__restrict__ stamps, int epoch,
-                                                        int *__restrict__ ctl) {
+                                                        double *__restrict__ xpub,
+                                                        double *__restrict__ xother, int capblk,
+                                                        int epoch, int *__restrict__ ctl) {
   if (blockIdx.x & 7) return;
   chain_check_xcc(epoch, ctl);
   __shared__ double part[4][64];
   __shared__ double rs[64];
   const int nblk = (N + 63) / 64;
-  const int b = nblk - 1 - (int)(blockIdx.x >> 3);  // last block first
+  const int w = (int)(blockIdx.x >> 3);
+  const int b = nblk - 1 - w;  // last block first
   const int b0 = b * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  chain_reset_other(xother, capblk, w, nblk);
   // inverse of the diagonal block, rows [16 wave, 16 wave + 16): inv[j][lane] -- parked in LDS
   // until the block's own turn.  All workers of a solve must be RESIDENT on the one XCD (32
   // CUs): a worker that starts late walks the whole chain behind the others.  In registers the
@@ -611,21 +645,26 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_chain(const double *__restrict
 #pragma unroll
     for (int t = 0; t < 16; ++t) lv[t] = (r0 + t < N) ? cp[(int64_t)t * ldk] : 0.0;
   };
+  // this wavefront's 16 entries of block a: lane t < 16 holds entry 16 wave + t (rows beyond N
+  // are never published and count as zero)
+  auto slot = [&](int a) { return xpub + a * 64 + 16 * wave + lane; };
+  auto wanted = [&](int a) { return lane < 16 && a * 64 + 16 * wave + lane < N; };
   double acc = 0.0;
   double cur[16], nxt[16];
   int a = nblk - 1;
-  if (a > b) fetch(a, cur);
+  long long pend = 0;
+  if (a > b) {
+    fetch(a, cur);
+    if (wanted(a)) pend = chain_peek(slot(a));
+  }
   for (; a > b; --a) {
     if (a - 1 > b) fetch(a - 1, nxt);
-    chain_wait(stamps + a, epoch, ctl);
-    const int xr0 = a * 64 + 16 * wave;
+    const double xa = chain_take(slot(a), wanted(a), pend, ctl);
+    // the next block's entries are asked for now: behind the front they are there already
+    pend = 0;
+    if (a - 1 > b && wanted(a - 1)) pend = chain_peek(slot(a - 1));
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const double xv = (xr0 + t < N) ? __hip_atomic_load(x + xr0 + t, __ATOMIC_RELAXED,
-                                                          __HIP_MEMORY_SCOPE_AGENT)
-                                      : 0.0;
-      acc = fma(cur[t], xv, acc);
-    }
+    for (int t = 0; t < 16; ++t) acc = fma(cur[t], chain_bcast(xa, t), acc);
 #pragma unroll
     for (int t = 0; t < 16; ++t) cur[t] = nxt[t];
   }
@@ -641,16 +680,12 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_chain(const double *__restrict
   __syncthreads();
   if (wave == 0) {
     const double xv = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-    if (b0 + lane < N)
-      // plain stores (x, then the stamp): they stay in the XCD's L2, where the consumers'
-      // L1-bypassing loads find them; sc1 stores are write-through AND drop the line from L2,
-      // so every consumer load went out to the fabric (back-solve step 0.51 -> 0.49 ms)
+    if (b0 + lane < N) {
+      // plain stores: they stay in the XCD's L2, where the consumers' L1-bypassing loads find
+      // them (sc1 stores are write-through AND drop the line from L2)
+      xpub[b0 + lane] = xv;
       x[b0 + lane] = xv;
-    // the stores above must have reached L2 before the stamp does: two stores of one
-    // wavefront to different L2 channels are not ordered otherwise (inline asm: the compiler
-    // may drop a builtin wait it believes redundant; the clobber also pins the order)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) stamps[b] = epoch;
+    }
   }
 }
 
@@ -658,15 +693,18 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_chain(const double *__restrict
 __global__ __launch_bounds__(256) void k_trsv_fwd_chain(const double *__restrict__ K, int64_t ldk,
                                                         const double *__restrict__ LinvT,
                                                         const double *z, double *x, int N,
-                                                        int *__restrict__ stamps, int epoch,
-                                                        int *__restrict__ ctl) {
+                                                        double *__restrict__ xpub,
+                                                        double *__restrict__ xother, int capblk,
+                                                        int epoch, int *__restrict__ ctl) {
   if (blockIdx.x & 7) return;
   chain_check_xcc(epoch, ctl);
   __shared__ double part[4][64];
   __shared__ double rs[64];
+  const int nblk = (N + 63) / 64;
   const int b = (int)(blockIdx.x >> 3);  // first block first
   const int b0 = b * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  chain_reset_other(xother, capblk, b, nblk);
   // LinvT[j][i] = inv[i][j]: rows j in [16 wave, 16 wave + 16), column i = lane (parked in LDS,
   // see k_trsv_bwd_chain)
   __shared__ double ivs[64][64];
@@ -692,18 +730,23 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_chain(const double *__restrict
       lv[t + 1] = v.y;
     }
   };
+  // blocks a < b are full (only the last block of a solve can be ragged)
+  auto slot = [&](int a) { return xpub + a * 64 + 16 * wave + lane; };
+  const bool mine = lane < 16;
   double acc = 0.0;
   double cur[16], nxt[16];
-  if (b > 0) fetch(0, cur);
+  long long pend = 0;
+  if (b > 0) {
+    fetch(0, cur);
+    if (mine) pend = chain_peek(slot(0));
+  }
   for (int a = 0; a < b; ++a) {
     if (a + 1 < b) fetch(a + 1, nxt);
-    chain_wait(stamps + a, epoch, ctl);
-    const int xr0 = a * 64 + 16 * wave;
+    const double xa = chain_take(slot(a), mine, pend, ctl);
+    pend = 0;
+    if (a + 1 < b && mine) pend = chain_peek(slot(a + 1));
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const double xv = __hip_atomic_load(x + xr0 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      acc = fma(cur[t], xv, acc);
-    }
+    for (int t = 0; t < 16; ++t) acc = fma(cur[t], chain_bcast(xa, t), acc);
 #pragma unroll
     for (int t = 0; t < 16; ++t) cur[t] = nxt[t];
   }
@@ -719,16 +762,10 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_chain(const double *__restrict
   __syncthreads();
   if (wave == 0) {
     const double xv = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-    if (b0 + lane < N)
-      // plain stores (x, then the stamp): they stay in the XCD's L2, where the consumers'
-      // L1-bypassing loads find them; sc1 stores are write-through AND drop the line from L2,
-      // so every consumer load went out to the fabric (back-solve step 0.51 -> 0.49 ms)
+    if (b0 + lane < N) {
+      xpub[b0 + lane] = xv;
       x[b0 + lane] = xv;
-    // the stores above must have reached L2 before the stamp does: two stores of one
-    // wavefront to different L2 channels are not ordered otherwise (inline asm: the compiler
-    // may drop a builtin wait it believes redundant; the clobber also pins the order)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) stamps[b] = epoch;
+    }
   }
 }
 
@@ -1243,6 +1280,9 @@ hipError_t ldlt_alloc(DenseLdlt &f, int Nmax, hipStream_t stream) {
   f.chain_stride = (int)(rows / 64 + 2);
   if ((e = hipMalloc(&f.chain, (2 * f.chain_stride + 4) * sizeof(int))) != hipSuccess) return e;
   if ((e = hipMemset(f.chain, 0, (2 * f.chain_stride + 4) * sizeof(int))) != hipSuccess) return e;
+  // publication halves of the chained solves, every slot = the sentinel (all bits set)
+  if ((e = hipMalloc(&f.xpub, 2 * (size_t)f.chain_stride * 64 * sizeof(double))) != hipSuccess) return e;
+  if ((e = hipMemset(f.xpub, 0xff, 2 * (size_t)f.chain_stride * 64 * sizeof(double))) != hipSuccess) return e;
   if ((e = hipMalloc(&f.hctl, 16 * sizeof(int))) != hipSuccess) return e;
   if ((e = hipMemset(f.hctl, 0, 16 * sizeof(int))) != hipSuccess) return e;
   if ((e = hipHostMalloc(&f.h_flags, 4 * sizeof(int))) != hipSuccess) return e;
@@ -1260,6 +1300,7 @@ void ldlt_free(DenseLdlt &f) {
   if (f.LinvT) (void)hipFree(f.LinvT);
   if (f.flags) (void)hipFree(f.flags);
   if (f.chain) (void)hipFree(f.chain);
+  if (f.xpub) (void)hipFree(f.xpub);
   if (f.hctl) (void)hipFree(f.hctl);
   if (f.h_flags) (void)hipHostFree(f.h_flags);
   f = DenseLdlt();
@@ -1402,6 +1443,8 @@ int ldlt_chain_check(DenseLdlt &f) {
   f.h_flags[3] = 0;
   g_chain_off = true;
   (void)hipMemsetAsync(f.chain + 2 * f.chain_stride + 1, 0, sizeof(int), f.stream);
+  // a solve that timed out may have left its half partly published
+  (void)hipMemsetAsync(f.xpub, 0xff, 2 * (size_t)f.chain_stride * 64 * sizeof(double), f.stream);
   return bad;
 }
 
@@ -1429,8 +1472,11 @@ hipError_t ldlt_backsolve_async(DenseLdlt &f, const double *w, double *sol) {
   if (N == 0) return hipSuccess;
   if (use_chain()) {
     const int nblk = (N + 63) / 64;
+    const int ep = ++f.chain_epoch;
+    const size_t half = (size_t)f.chain_stride * 64;
     hipLaunchKernelGGL(k_trsv_bwd_chain, dim3(8 * nblk), dim3(256), 0, s, f.K, f.ldk, f.Linv, w, sol,
-                       N, f.chain, ++f.chain_epoch, f.chain + 2 * f.chain_stride);
+                       N, f.xpub + (ep & 1) * half, f.xpub + ((ep + 1) & 1) * half, f.chain_stride,
+                       ep, f.chain + 2 * f.chain_stride);
     return chain_report(f, sol);
   }
   hipLaunchKernelGGL(k_vec_copy_strided, dim3((N + 255) / 256), dim3(256), 0, s, f.zwork, w, N);
@@ -1451,9 +1497,11 @@ hipError_t ldlt_solve_async(DenseLdlt &f, const double *rhs, double *sol) {
   // forward: L y = rhs  (y lands in sol)
   if (use_chain()) {
     const int nblk = (N + 63) / 64;
+    const int ep = ++f.chain_epoch;
+    const size_t half = (size_t)f.chain_stride * 64;
     hipLaunchKernelGGL(k_trsv_fwd_chain, dim3(8 * nblk), dim3(256), 0, s, f.K, f.ldk, f.LinvT, rhs,
-                       sol, N, f.chain + f.chain_stride, ++f.chain_epoch,
-                       f.chain + 2 * f.chain_stride);
+                       sol, N, f.xpub + (ep & 1) * half, f.xpub + ((ep + 1) & 1) * half,
+                       f.chain_stride, ep, f.chain + 2 * f.chain_stride);
   } else {
     hipLaunchKernelGGL(k_vec_copy_strided, dim3((N + 255) / 256), dim3(256), 0, s, f.zwork, rhs, N);
     for (int c0 = 0; c0 < N; c0 += 256) {
