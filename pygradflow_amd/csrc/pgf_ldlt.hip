@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_chain(const double *__restrict
   // are never published and count as zero)
   auto slot = [&](int a) { return xpub + a * 64 + 16 * wave + lane; };
   auto wanted = [&](int a) { return lane < 16 && a * 64 + 16 * wave + lane < N; };
-  double acc = 0.0;
+  double acc4[4] = {0.0, 0.0, 0.0, 0.0};
   double cur[16], nxt[16];
   int a = nblk - 1;
   long long pend = 0;
@@ -663,20 +663,21 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_chain(const double *__restrict
     // the next block's entries are asked for now: behind the front they are there already
     pend = 0;
     if (a - 1 > b && wanted(a - 1)) pend = chain_peek(slot(a - 1));
+    // four independent sums: a dependent fp64 FMA of a lone wavefront costs ~35 cycles
 #pragma unroll
-    for (int t = 0; t < 16; ++t) acc = fma(cur[t], chain_bcast(xa, t), acc);
+    for (int t = 0; t < 16; ++t) acc4[t & 3] = fma(cur[t], chain_bcast(xa, t), acc4[t & 3]);
 #pragma unroll
     for (int t = 0; t < 16; ++t) cur[t] = nxt[t];
   }
-  part[wave][lane] = acc;
+  part[wave][lane] = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
   __syncthreads();
   if (wave == 0) rs[lane] = zb - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
   __syncthreads();
   // x_i = sum_j inv[j][i] r_j  (j >= i; the stored inverse is zero above the diagonal)
-  double s = 0.0;
+  double s4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int t = 0; t < 16; ++t) s = fma(ivs[16 * wave + t][lane], rs[16 * wave + t], s);
-  part[wave][lane] = s;
+  for (int t = 0; t < 16; ++t) s4[t & 3] = fma(ivs[16 * wave + t][lane], rs[16 * wave + t], s4[t & 3]);
+  part[wave][lane] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
   __syncthreads();
   if (wave == 0) {
     const double xv = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_chain(const double *__restrict
   // blocks a < b are full (only the last block of a solve can be ragged)
   auto slot = [&](int a) { return xpub + a * 64 + 16 * wave + lane; };
   const bool mine = lane < 16;
-  double acc = 0.0;
+  double acc4[4] = {0.0, 0.0, 0.0, 0.0};
   double cur[16], nxt[16];
   long long pend = 0;
   if (b > 0) {
@@ -745,20 +746,21 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_chain(const double *__restrict
     const double xa = chain_take(slot(a), mine, pend, ctl);
     pend = 0;
     if (a + 1 < b && mine) pend = chain_peek(slot(a + 1));
+    // four independent sums: a dependent fp64 FMA of a lone wavefront costs ~35 cycles
 #pragma unroll
-    for (int t = 0; t < 16; ++t) acc = fma(cur[t], chain_bcast(xa, t), acc);
+    for (int t = 0; t < 16; ++t) acc4[t & 3] = fma(cur[t], chain_bcast(xa, t), acc4[t & 3]);
 #pragma unroll
     for (int t = 0; t < 16; ++t) cur[t] = nxt[t];
   }
-  part[wave][lane] = acc;
+  part[wave][lane] = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
   __syncthreads();
   if (wave == 0) rs[lane] = zb - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
   __syncthreads();
   // y_i = sum_j inv[i][j] r_j
-  double s = 0.0;
+  double s4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int t = 0; t < 16; ++t) s = fma(ivs[16 * wave + t][lane], rs[16 * wave + t], s);
-  part[wave][lane] = s;
+  for (int t = 0; t < 16; ++t) s4[t & 3] = fma(ivs[16 * wave + t][lane], rs[16 * wave + t], s4[t & 3]);
+  part[wave][lane] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
   __syncthreads();
   if (wave == 0) {
     const double xv = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
