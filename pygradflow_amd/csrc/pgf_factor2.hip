@@ -191,10 +191,15 @@ __global__ __launch_bounds__(256) void kb_update_diag(const BInst *__restrict__ 
 // k = 8 (q / 2) + 2 l4 + (q & 1), so that both operands come as aligned 16-byte pairs.
 // 16 rows per workgroup because the MFMA work of a workgroup runs on ONE CU's matrix pipes
 // (0.3 TFLOP/s): 64 rows took 34 us.
+// POST (k_trsm_ud): after the stores of sub-panel s have reached L2 the workgroup posts
+// post[s] = postval -- the update of the next diagonal block runs in the same launch and takes
+// the rows sub-panel by sub-panel.
+template <bool POST = false>
 __device__ __forceinline__ void trsm_block_body(double (*Xs)[16][C_LD], double *ds, int wg, double *K,
                                                 int64_t ldk, double *W, int64_t ldw, int nrows,
                                                 int c0, int nb, const double *__restrict__ dinv,
-                                                const double *__restrict__ Linv) {
+                                                const double *__restrict__ Linv, int *post = nullptr,
+                                                int postval = 0) {
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int bend = c0 + nb;
@@ -289,7 +294,15 @@ __device__ __forceinline__ void trsm_block_body(double (*Xs)[16][C_LD], double *
             kp[0] = l.x;
           }
         }
+        if (POST) {
+          // every thread's stores are in L2 (the L1 is write-through) before the stamp is
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (tid == 0) post[s] = postval;
+        }
       }
+    } else if (POST) {
+      if (tid == 0) post[s] = postval;  // no such sub-panel (ragged last block): nothing to wait for
     }
   }
 }
@@ -511,6 +524,143 @@ __device__ __forceinline__ void help_check_xcc(int *hc, int epoch, int *flags) {
 }
 __device__ __forceinline__ double ld_agent(const double *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ------------------------------------------------------------------ T(k) + U_diag in ONE launch
+// k_update_diag (k -> k + 1) only needs the rows of the NEXT diagonal block from T(k): the (at
+// most) 16 row groups right below block k.  As its own launch it cost 7.9 us per outer block on
+// the factorisation's critical path.  Here those row groups and the 36 diagonal tiles are
+// workgroups of one launch on ONE XCD (ids that are multiples of 8, checked through
+// HW_REG_XCC_ID like the chain's helpers): a row group posts a stamp per 64-column sub-panel once
+// the sub-panel's W / L entries are in that XCD's L2, a diagonal tile takes its K-depth-256
+// product sub-panel by sub-panel behind the stamps of the four row groups it reads (operands
+// with L1-bypassing loads) and is done about 2 us after the last one -- inside the time the
+// other ~290 row groups of T(k) take anyway.  Workgroups only wait for workgroups with smaller
+// ids; polls are bounded; a failed placement check or a timed-out wait sets flags[2] and the
+// host repeats the factorisation with separate launches (as for the chain's helpers).
+#define TUD_BASE 32  // hctl words [32, 96): stamp of (row group g < 16, sub-panel s < 4) at 4 g + s
+
+// wait until the four row groups (g0, g0 + 1, g1, g1 + 1) have posted sub-panel s
+__device__ __forceinline__ void tud_wait(const int *st, int g0, int g1, int s, int val, int ngroups,
+                                         int *flags) {
+  const int lane = threadIdx.x & 63;
+  int g = (lane < 2) ? g0 + lane : g1 + (lane - 2);
+  const bool mine = lane < 4 && g < ngroups;
+  for (int it = 0; it < HELP_SPIN_LIMIT; ++it) {
+    int v = val;
+    if (mine) v = __hip_atomic_load(st + 4 * g + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool same_epoch = (v >> 4) == (val >> 4);
+    if (!__builtin_amdgcn_ballot_w64(!same_epoch)) {
+      if (__builtin_amdgcn_ballot_w64(v != val)) atomicOr(&flags[2], 1);  // another XCD
+      return;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  atomicOr(&flags[2], 2);
+}
+
+// update_diag_tile<32> behind the stamps: chunk kk = sub-panel kk / 64
+__device__ __forceinline__ void update_diag_tile_live(unsigned char *smem, int t, double *K, int64_t ldk,
+                                                      const double *W, int64_t ldw, int kc0, int kd,
+                                                      int c1, int nb1, const int *st, int val,
+                                                      int ngroups, int *flags) {
+  constexpr int TS = 32, WPR = 2, NT = 256, NQ = 4;
+  double(*As)[C_LD] = reinterpret_cast<double(*)[C_LD]>(smem);
+  double(*Bs)[C_LD] = reinterpret_cast<double(*)[C_LD]>(smem + TS * C_LD * 8);
+  int I = 0;
+  while (t > I) {
+    t -= I + 1;
+    ++I;
+  }
+  const int J = t;  // J <= I
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WPR, wc = wave % WPR, l15 = lane & 15, l4 = lane >> 4;
+  const int lim = c1 + nb1;
+  const int i0 = c1 + TS * I, j0 = c1 + TS * J;
+  double4_t acc;
+  const int j = j0 + 16 * wc + l15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = i0 + 16 * wr + l4 + 4 * r;
+    acc[r] = (i < lim && j < lim && j <= i) ? K[(int64_t)i * ldk + j] : 0.0;
+  }
+  const double *B = K + kc0;
+  for (int kk = 0; kk < kd; kk += 64) {
+    const int kc = min(64, kd - kk);
+    tud_wait(st, 2 * I, 2 * J, kk >> 6, val, ngroups, flags);
+    double2_t va[NQ], vb[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int p = q * NT + tid;
+      const int row = p >> 5, c2 = (p & 31) * 2;
+      double2_t a = (double2_t){0.0, 0.0}, b = (double2_t){0.0, 0.0};
+      if (i0 + row < lim) {
+        const double *src = W + (int64_t)(i0 + row) * ldw + kk + c2;
+        if (c2 < kc) a.x = ld_agent(src);
+        if (c2 + 1 < kc) a.y = ld_agent(src + 1);
+      }
+      if (j0 + row < lim) {
+        const double *src = B + (int64_t)(j0 + row) * ldk + kk + c2;
+        if (c2 < kc) b.x = ld_agent(src);
+        if (c2 + 1 < kc) b.y = ld_agent(src + 1);
+      }
+      va[q] = a;
+      vb[q] = b;
+    }
+    __syncthreads();  // the previous chunk's fragment reads are done
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int p = q * NT + tid;
+      const int row = p >> 5, c2 = (p & 31) * 2;
+      *reinterpret_cast<double2_t *>(&As[row][c2]) = -va[q];
+      *reinterpret_cast<double2_t *>(&Bs[row][c2]) = vb[q];
+    }
+    __syncthreads();
+    const int kr = (kc + 3) & ~3;
+#pragma unroll 4
+    for (int ks = 0; ks < kr; ks += 4) {
+      const double a = As[16 * wr + l15][ks + l4];
+      const double b = Bs[16 * wc + l15][ks + l4];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = i0 + 16 * wr + l4 + 4 * r;
+    if (i < lim && j < lim && j <= i) K[(int64_t)i * ldk + j] = acc[r];
+  }
+}
+
+// grid: tud_grid() workgroups.  nA = row groups of the next diagonal block, nU = its tiles,
+// S = nA + nU special workgroups at the ids 8 q; every other id takes one of the other row groups.
+__global__ __launch_bounds__(256) void k_trsm_ud(double *K, int64_t ldk, double *W, int64_t ldw,
+                                                 int nrows, int c0, int nb,
+                                                 const double *__restrict__ dinv,
+                                                 const double *__restrict__ Linv, int N, int *hctl,
+                                                 int epoch, int *flags) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 16 * C_LD * 8 + 256 * 8];
+  double(*Xs)[16][C_LD] = reinterpret_cast<double(*)[16][C_LD]>(smem);
+  double *ds = reinterpret_cast<double *>(smem + 4 * 16 * C_LD * 8);
+  const int c1 = c0 + nb, nb1 = min(256, N - c1);
+  const int nT = (nrows - c1 + 15) / 16;
+  const int nA = min(nT, (nb1 + 15) / 16);
+  const int nt = (nb1 + 31) / 32, nU = nt * (nt + 1) / 2;
+  const int S = nA + nU;
+  const int id = (int)blockIdx.x;
+  int *st = hctl + TUD_BASE;
+  const int val = ((epoch & 0x7ffffff) << 4) | (int)(__builtin_amdgcn_s_getreg(6164) & 15);
+  if (id < 8 * S && (id & 7) == 0) {
+    const int q = id >> 3;
+    if (q < nA) {
+      trsm_block_body<true>(Xs, ds, q, K, ldk, W, ldw, nrows, c0, nb, dinv, Linv, st + 4 * q, val);
+    } else {
+      update_diag_tile_live(smem, q - nA, K, ldk, W, ldw, c0, nb, c1, nb1, st, val, nA, flags);
+    }
+    return;
+  }
+  const int r = id < 8 * S ? id - (id >> 3) - 1 : id - S;
+  if (nA + r >= nT) return;
+  trsm_block_body<false>(Xs, ds, nA + r, K, ldk, W, ldw, nrows, c0, nb, dinv, Linv);
 }
 
 // inverse of the unit-lower 64 x 64 diagonal tile g of the block (rows / columns from b0), by
@@ -1340,13 +1490,21 @@ static int chain_waves() {
 // helper workgroups of the diagonal chain (PGF_CHAIN_HELP=0: the chain does everything itself);
 // switched off for the process after a failed placement check or a timed-out hand-over
 static bool g_help_off = false;
+static bool g_fused_ud_off = false;
 static bool chain_helpers() {
   static const bool on = !(getenv("PGF_CHAIN_HELP") && atoi(getenv("PGF_CHAIN_HELP")) == 0);
   return on && !g_help_off;
 }
-void ldlt_chain_helpers_off() { g_help_off = true; }
+void ldlt_chain_helpers_off() {
+  // (flags[2] does not say which of the in-launch hand-overs failed: both kinds go)
+  g_help_off = true;
+  g_fused_ud_off = true;
+}
 bool ldlt_chain_helpers_enabled() { return chain_helpers(); }
-void ldlt_chain_helpers_set(bool on) { g_help_off = !on; }
+void ldlt_chain_helpers_set(bool on) {
+  g_help_off = !on;
+  g_fused_ud_off = !on;
+}
 
 // test hook (pgf_debug_fail_next_helper): make the factorisation just enqueued look like one
 // whose helpers failed their checks
@@ -1365,6 +1523,13 @@ static int lazy_budget() {
 static int lazy_cap() {
   static const int c = getenv("PGF_LAZY_CAP") ? std::max(1, atoi(getenv("PGF_LAZY_CAP"))) : 2;
   return c;
+}
+
+// T(k) and the next diagonal block's update in one launch (k_trsm_ud); PGF_FUSED_UD=0 or a failed
+// placement check: two launches
+static bool fused_ud() {
+  static const bool on = !(getenv("PGF_FUSED_UD") && atoi(getenv("PGF_FUSED_UD")) == 0);
+  return on && !g_fused_ud_off;
 }
 
 static bool fused() {
@@ -1534,15 +1699,28 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
     }
     span_end(pr.chain_spans);
   };
+  // T(c0) -- with the update of the next diagonal block in the same launch (k_trsm_ud) unless
+  // per-kernel events are wanted or there is no next block
+  const bool fud = fused_ud() && !p;
   auto launch_t = [&](int c0, double *Wb) {
     const int nb = std::min(OB, N - c0);
     const int below = nrows - (c0 + nb);
-    if (below > 0) {
-      span_begin(pr.trsm_spans);
-      hipLaunchKernelGGL(k_trsm_block, dim3((below + 15) / 16), dim3(256), 0, s, f.K, f.ldk, Wb, ldw,
-                         nrows, c0, nb, f.dinv, f.Linv);
-      span_end(pr.trsm_spans);
+    if (below <= 0) return;
+    if (fud && c0 + nb < N) {
+      const int c1 = c0 + nb, nb1 = std::min(OB, N - c1);
+      const int nT = (below + 15) / 16, nA = std::min(nT, (nb1 + 15) / 16);
+      const int nt = (nb1 + 31) / 32, S = nA + nt * (nt + 1) / 2;
+      const int rest = nT - nA;  // row groups at the ordinary ids
+      const int last = rest > 0 ? (rest - 1 < 7 * S ? (rest - 1) + (rest - 1) / 7 + 1 : rest - 1 + S) : 0;
+      const int grid = std::max(8 * (S - 1) + 1, last + 1);
+      hipLaunchKernelGGL(k_trsm_ud, dim3(grid), dim3(256), 0, s, f.K, f.ldk, Wb, ldw, nrows, c0, nb,
+                         f.dinv, f.Linv, N, f.hctl, next_help_epoch(), f.flags);
+      return;
     }
+    span_begin(pr.trsm_spans);
+    hipLaunchKernelGGL(k_trsm_block, dim3((below + 15) / 16), dim3(256), 0, s, f.K, f.ldk, Wb, ldw,
+                       nrows, c0, nb, f.dinv, f.Linv);
+    span_end(pr.trsm_spans);
   };
   // Lazy trailing update (production; plan_updates above).  PGF_LAZY_BUDGET fixes the budget
   // (0 = no limit = the eager schedule: every launch applies its block everywhere).
@@ -1597,10 +1775,12 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
     const int c1 = c0 + OB, nb1 = std::min(OB, N - c1);
     const double *Wb = f.W + (size_t)buf * f.wstride;
     const int nt = (nb1 + 31) / 32;
-    span_begin(pr.udiag_spans);
-    hipLaunchKernelGGL(k_update_diag<32>, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, f.K, f.ldk, Wb,
-                       ldw, c0, OB, c1, nb1);
-    span_end(pr.udiag_spans);
+    if (!fud) {
+      span_begin(pr.udiag_spans);
+      hipLaunchKernelGGL(k_update_diag<32>, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, f.K, f.ldk, Wb,
+                         ldw, c0, OB, c1, nb1);
+      span_end(pr.udiag_spans);
+    }
     // D(k + 1) beside trailing-update work, in one launch; while profiling (per-kernel events)
     // and on request (PGF_FUSED=0) D(k + 1) and the whole of U(k) as two launches
     if (lazy) {

@@ -1285,8 +1285,9 @@ hipError_t ldlt_alloc(DenseLdlt &f, int Nmax, hipStream_t stream) {
   // publication halves of the chained solves, every slot = the sentinel (all bits set)
   if ((e = hipMalloc(&f.xpub, 2 * (size_t)f.chain_stride * 64 * sizeof(double))) != hipSuccess) return e;
   if ((e = hipMemset(f.xpub, 0xff, 2 * (size_t)f.chain_stride * 64 * sizeof(double))) != hipSuccess) return e;
-  if ((e = hipMalloc(&f.hctl, 16 * sizeof(int))) != hipSuccess) return e;
-  if ((e = hipMemset(f.hctl, 0, 16 * sizeof(int))) != hipSuccess) return e;
+  // [0, 16): chain <-> helpers, [32, 96): row groups of T(k) -> tiles of the next diagonal block
+  if ((e = hipMalloc(&f.hctl, 128 * sizeof(int))) != hipSuccess) return e;
+  if ((e = hipMemset(f.hctl, 0, 128 * sizeof(int))) != hipSuccess) return e;
   if ((e = hipHostMalloc(&f.h_flags, 4 * sizeof(int))) != hipSuccess) return e;
   for (int i = 0; i < 4; ++i) f.h_flags[i] = 0;
   return hipSuccess;

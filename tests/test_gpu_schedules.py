@@ -17,6 +17,7 @@ VARIANTS = {
     "no_helpers": {"PGF_CHAIN_HELP": "0"},
     "chain_8_wavefronts": {"PGF_CHAIN_WAVES": "8"},
     "unfused_launches": {"PGF_FUSED": "0"},
+    "separate_update_diag": {"PGF_FUSED_UD": "0"},
     "eager_update_plan": {"PGF_LAZY_BUDGET": "0"},
     "tight_update_budget": {"PGF_LAZY_BUDGET": "40", "PGF_LAZY_CAP": "1"},
     "legacy_schedule": {"PGF_FACTOR": "1"},
