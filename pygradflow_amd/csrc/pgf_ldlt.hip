@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_chain(const double *__restrict
 }
 
 // forward: L y = z.  y_b = inv(L_bb) (z_b - sum_{a < b} L_ba y_a).  In place ok.
-__global__ __launch_bounds__(256) void k_trsv_fwd_chain(const double *__restrict__ K, int64_t ldk,
+__global__ __launch_bounds__(256, 3) void k_trsv_fwd_chain(const double *__restrict__ K, int64_t ldk,
                                                         const double *__restrict__ LinvT,
                                                         const double *z, double *x, int N,
                                                         double *__restrict__ xpub,
@@ -715,13 +715,25 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_chain(const double *__restrict
     for (int t = 0; t < 16; ++t) ivs[16 * wave + t][lane] = ip[t * 64];
   }
   const double zb = (wave == 0 && b0 + lane < N) ? z[b0 + lane] : 0.0;
-  // lane <-> ROW b0 + lane; wavefront w takes columns [16 w, 16 w + 16) of every block a: 128
-  // contiguous bytes per lane (one cache line each, not coalesced across lanes), so that the
-  // multiplier x_a[t] is wavefront-uniform and no cross-lane reduction sits on the hand-over
-  // path (a coalesced layout with 16 row sums over the lanes made the forward chain 2x slower
-  // than the backward one)
-  const bool row_ok = b0 + lane < N;
+  // Wavefront w takes columns [16 w, 16 w + 16) of every block a.  Two layouts:
+  //  * blocks a < b - 1 (the bulk: 3160 of the 3240 blocks at N = 5120) COALESCED: lane
+  //    (r4, c) = (lane >> 4, lane & 15) holds column 16 w + c of the rows 4 i + r4, i < 16 --
+  //    four full cache lines per load instruction -- its multiplier is the published entry
+  //    16 w + c (all four lane groups poll the same 16 words, no broadcast), and the 16 row sums
+  //    over c are formed ONCE, by a reduce-scatter over the 16-lane groups while the wavefront
+  //    waits for the last block's entries.
+  //  * block b - 1 (the hand-over path) with lane <-> ROW: 128 contiguous bytes per lane, the
+  //    multipliers wavefront-uniform (v_readlane), no cross-lane reduction behind the wait.
+  // With lane <-> row for every block the 64 cache lines per load instruction made the ONE
+  // XCD's texture addressers the bound: 2.2 us per hand-over against 1.4 us backward.
+  const int r4 = lane >> 4, c = lane & 15;
   auto fetch = [&](int a, double (&lv)[16]) {
+    const double *rp = K + (int64_t)(b0 + r4) * ldk + a * 64 + 16 * wave + c;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lv[i] = (b0 + 4 * i + r4 < N) ? rp[(int64_t)(4 * i) * ldk] : 0.0;
+  };
+  const bool row_ok = b0 + lane < N;
+  auto fetch_rows = [&](int a, double (&lv)[16]) {
     const double *rp = K + (int64_t)(b0 + lane) * ldk + a * 64 + 16 * wave;
 #pragma unroll
     for (int t = 0; t < 16; t += 2) {
@@ -732,27 +744,57 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_chain(const double *__restrict
     }
   };
   // blocks a < b are full (only the last block of a solve can be ragged)
-  auto slot = [&](int a) { return xpub + a * 64 + 16 * wave + lane; };
-  const bool mine = lane < 16;
-  double acc4[4] = {0.0, 0.0, 0.0, 0.0};
+  __shared__ double bulk[4][64];
+  const int nbulk = b - 1;  // blocks 0 .. b - 2
+  // (the last block's rows travel in the prefetch registers of the bulk loop: behind the last
+  // bulk block there is nothing else to fetch)
   double cur[16], nxt[16];
-  long long pend = 0;
-  if (b > 0) {
-    fetch(0, cur);
-    if (mine) pend = chain_peek(slot(0));
+  if (b == 1) fetch_rows(0, cur);
+  {
+    auto slot = [&](int a) { return xpub + a * 64 + 16 * wave + c; };
+    double acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+    long long pend = 0;
+    if (nbulk > 0) {
+      fetch(0, cur);
+      pend = chain_peek(slot(0));
+    }
+    for (int a = 0; a < nbulk; ++a) {
+      if (a + 1 < nbulk) fetch(a + 1, nxt);
+      else fetch_rows(b - 1, nxt);
+      const double xa = chain_take(slot(a), true, pend, ctl);
+      pend = 0;
+      if (a + 1 < nbulk) pend = chain_peek(slot(a + 1));
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = fma(cur[i], xa, acc[i]);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) cur[i] = nxt[i];
+    }
+    // reduce-scatter over c: lane (r4, c) ends with the sum of row 4 c + r4
+    double v8[8], v4[4], v2[2];
+    const bool h3 = c & 8, h2 = c & 4, h1 = c & 2, h0 = c & 1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      v8[j] = (h3 ? acc[j + 8] : acc[j]) + __shfl_xor(h3 ? acc[j] : acc[j + 8], 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v4[j] = (h2 ? v8[j + 4] : v8[j]) + __shfl_xor(h2 ? v8[j] : v8[j + 4], 4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) v2[j] = (h1 ? v4[j + 2] : v4[j]) + __shfl_xor(h1 ? v4[j] : v4[j + 2], 2);
+    bulk[wave][4 * c + r4] = (h0 ? v2[1] : v2[0]) + __shfl_xor(h0 ? v2[0] : v2[1], 1);
   }
-  for (int a = 0; a < b; ++a) {
-    if (a + 1 < b) fetch(a + 1, nxt);
-    const double xa = chain_take(slot(a), mine, pend, ctl);
-    pend = 0;
-    if (a + 1 < b && mine) pend = chain_peek(slot(a + 1));
+  double accr = 0.0;
+  if (b > 0) {
+    const bool mine = lane < 16;
+    const double *sl = xpub + (b - 1) * 64 + 16 * wave + lane;
+    const double xa = chain_take(sl, mine, mine ? chain_peek(sl) : 0, ctl);
     // four independent sums: a dependent fp64 FMA of a lone wavefront costs ~35 cycles
+    double acc4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc4[t & 3] = fma(cur[t], chain_bcast(xa, t), acc4[t & 3]);
-#pragma unroll
-    for (int t = 0; t < 16; ++t) cur[t] = nxt[t];
+    accr = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
   }
-  part[wave][lane] = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+  part[wave][lane] = accr + bulk[wave][lane];  // (own wavefront's LDS words: in program order)
   __syncthreads();
   if (wave == 0) rs[lane] = zb - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
   __syncthreads();
