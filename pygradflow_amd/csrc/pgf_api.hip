@@ -66,6 +66,7 @@ struct pgf_solver {
   // with the same factor (same backward error, other right-hand sides) skip the check
   bool factor_clean = false;
   bool rs_skipped = false;
+  bool sp_guarded = false;  // banded path: the last solve carried the residual check (k_band_residual)
 };
 
 struct pgf_linsolver {
@@ -215,7 +216,8 @@ int pgf_destroy(pgf_handle h) {
     SparseDev &sp = h->sp;
     void *sps[] = {sp.pos, sp.Hptr, sp.Hrow, sp.Hcol, sp.Hslot, sp.Jptr, sp.Jcol, sp.Jslot, sp.JTptr,
                    sp.JTrow, sp.JTmap, sp.Hval, sp.Jval, sp.band, sp.brhs, sp.Hb0, sp.Jb0,
-                   sp.bD, sp.bL, sp.bU, sp.bDinv, sp.bF, sp.bX, sp.bneg};
+                   sp.bD, sp.bL, sp.bU, sp.bDinv, sp.bF, sp.bX, sp.bneg, sp.brhs0, sp.bres, sp.bsol,
+                   sp.bred};
     for (void *q : sps)
       if (q) (void)hipFree(q);
   }
@@ -484,7 +486,7 @@ static int factor_async(pgf_handle h, bool with_rhs) {
     if (h->sp.bw <= 8 && !getenv("PGF_BAND_SEQ")) {
       // cyclic-reduction mode keeps the assembled band intact; run one reduction (on
       // whatever right-hand side is there) only to obtain the pivot flags / inertia
-      sp_launch_bcr_solve(h->stream, h->sp, h->n + h->m, h->fac.flags);
+      sp_launch_bcr_solve(h->stream, h->sp, h->n + h->m, h->fac.flags, /*guard=*/false);
     } else {
       sp_launch_factor(h->stream, h->sp, h->n + h->m, h->fac.flags);
     }
@@ -560,8 +562,10 @@ static double residual_rel(pgf_handle h) {
 // partial pivoting of pgf_lu.hip (kept for the back-solve steps that follow).  Only when that
 // fails too does the call report PGF_SINGULAR -> LinearSolverError -> the step controller's
 // reject-and-halve path.
+static int sparse_refine(pgf_handle h, bool swapped, bool with_step);
 static int refine_if_needed(pgf_handle h, bool swapped, bool with_step = true) {
-  if (h->sparse || !h->refine_mode || h->N == 0 || h->rs_skipped) return PGF_OK;
+  if (h->sparse) return sparse_refine(h, swapped, with_step);
+  if (!h->refine_mode || h->N == 0 || h->rs_skipped) return PGF_OK;
   double rel = residual_rel(h);
   h->stat_last_rel = rel;
   if (h->last_solve == 1) h->factor_clean = rel <= 1e-3 * h->refine_tol;
@@ -622,6 +626,59 @@ static int refine_if_needed(pgf_handle h, bool swapped, bool with_step = true) {
   h->stat_last_rel = rel;
   if (!(rel <= h->refine_fail))
     return fail(h, PGF_SINGULAR, "reduced KKT system could not be solved to a small residual");
+  return PGF_OK;
+}
+
+// The same guard for the banded path (block cyclic reduction inverts its 8 x 8 pivot blocks
+// without pivoting, which is only safe while K is quasi-definite): after a host
+// synchronisation, max |rhs - K s| of the guarded solve (k_band_residual, K read from the intact
+// band) against refine_tol max |rhs|; beyond that up to two refinement steps -- one more
+// reduction on the residual each -- and PGF_SINGULAR when the residual stays above refine_fail:
+// the step controller then rejects the step and doubles lambda, which is what makes the
+// matrix quasi-definite again (the reference's own recovery path, step_control.py:80-107).
+static int sparse_refine(pgf_handle h, bool swapped, bool with_step) {
+  if (!h->refine_mode || !h->sp_guarded) return PGF_OK;
+  const int Nf = h->n + h->m;
+  if (Nf == 0) return PGF_OK;
+  double rel = residual_rel(h);
+  h->stat_last_rel = rel;
+  if (rel <= h->refine_tol) return PGF_OK;
+  hipStream_t s = h->stream;
+  SparseDev &sp = h->sp;
+  auto unswap = [&]() {
+    if (swapped) {
+      std::swap(h->x, h->xn);
+      std::swap(h->y, h->yn);
+    }
+  };
+  for (int it = 0; it < 2 && rel > h->refine_tol && rel < 1.0; ++it) {
+    HIPCHK(h, hipMemcpyAsync(sp.bsol, sp.brhs, (size_t)Nf * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(sp.brhs, sp.bres, (size_t)Nf * sizeof(double), hipMemcpyDeviceToDevice, s));
+    sp_launch_bcr_solve(s, sp, Nf, h->fac.flags, /*guard=*/false);
+    sp_launch_band_axpy(s, Nf, sp.bsol, sp.brhs);
+    sp_launch_band_residual(s, sp, Nf, /*reset=*/true);
+    HIPCHK(h, hipMemcpyAsync(h->h_rs, sp.bred, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (with_step) {
+      unswap();
+      sp_launch_step_update(s, sp, h->n, h->m, h->fact, h->rho, h->x, h->y, h->lb, h->ub, h->F, h->dx,
+                            h->dy, h->xn, h->yn, h->red);
+      launch_final_reduce(s, h->red, (h->n + h->m + 255) / 256, h->scal, 1);
+      unswap();
+      HIPCHK(h, hipMemcpyAsync(h->h_scal, h->scal, sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(h, hipStreamSynchronize(s));
+    ++h->stat_refined;
+    const double now = residual_rel(h);
+    if (!(now < rel)) {
+      rel = now;
+      break;
+    }
+    rel = now;
+  }
+  h->stat_last_rel = rel;
+  if (!(rel <= h->refine_fail))
+    return fail(h, PGF_SINGULAR,
+                "banded KKT system could not be solved to a small residual (unpivoted block cyclic reduction)");
   return PGF_OK;
 }
 
@@ -690,7 +747,10 @@ static int newton_core_async(pgf_handle h, bool *did_factor) {
         }
         (void)hipEventRecord(e0, s);
       }
-      sp_launch_bcr_solve(s, h->sp, Nf, h->fac.flags);
+      sp_launch_bcr_solve(s, h->sp, Nf, h->fac.flags, h->refine_mode != 0);
+      h->sp_guarded = h->refine_mode != 0;
+      if (h->sp_guarded)
+        (void)hipMemcpyAsync(h->h_rs, h->sp.bred, 2 * sizeof(double), hipMemcpyDeviceToHost, s);
       if (e0) {
         (void)hipEventRecord(e1, s);
         h->prof.update_spans.emplace_back(e0, e1);
@@ -702,6 +762,7 @@ static int newton_core_async(pgf_handle h, bool *did_factor) {
                                hipMemcpyDeviceToHost, s));
       *did_factor = true;  // flags need checking at the sync
     } else {
+      h->sp_guarded = false;
       if (!h->fac.factored) {
         int rc;
         if ((rc = factor_async(h, true))) return rc;
@@ -822,8 +883,12 @@ int pgf_linear_solve(pgf_handle h, const double *rhs, int trans, double *sol) {
     if (h->sp.bw <= 8 && !getenv("PGF_BAND_SEQ")) {
       // cyclic reduction keeps the assembled band intact: (re)assemble only when stale
       if (!h->fac.factored) sp_launch_assemble(h->stream, h->sp, h->n, h->m, h->mask, h->lamb, h->delta);
-      sp_launch_bcr_solve(h->stream, h->sp, Nf, h->fac.flags);
+      sp_launch_bcr_solve(h->stream, h->sp, Nf, h->fac.flags, h->refine_mode != 0);
+      h->sp_guarded = h->refine_mode != 0;
+      if (h->sp_guarded)
+        HIPCHK(h, hipMemcpyAsync(h->h_rs, h->sp.bred, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     } else {
+      h->sp_guarded = false;
       if (!h->fac.factored) {
         sp_launch_assemble(h->stream, h->sp, h->n, h->m, h->mask, h->lamb, h->delta);
         sp_launch_factor(h->stream, h->sp, Nf, h->fac.flags);  // forward-substitutes brhs on the way
@@ -834,6 +899,14 @@ int pgf_linear_solve(pgf_handle h, const double *rhs, int trans, double *sol) {
     }
     HIPCHK(h, hipMemcpyAsync(h->fac.h_flags, h->fac.flags, 4 * sizeof(int), hipMemcpyDeviceToHost,
                              h->stream));
+    if (h->sp_guarded) {  // residual check (and refinement) before the solution leaves
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      if (h->fac.h_flags[0]) return fail(h, PGF_SINGULAR, "zero or non-finite pivot in the banded KKT factorisation");
+      const int nneg = h->fac.h_flags[1];
+      if ((rc = sparse_refine(h, false, false))) return rc;
+      h->fac.h_flags[0] = 0;
+      h->fac.h_flags[1] = nneg;
+    }
     sp_launch_permute(h->stream, h->sp, Nf, h->sp.brhs, h->sol, 1);
     if ((rc = down(h, sol, h->sol, (size_t)Nf * sizeof(double)))) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -943,7 +1016,7 @@ int pgf_sparse_set_pattern(pgf_handle h, int bw, const int *pos, int nnzH, const
   if ((rc = up_new(h, &sp.JTrow, JTrow, (size_t)nnzJ))) return rc;
   if ((rc = up_new(h, &sp.JTmap, JTmap, (size_t)nnzJ))) return rc;
   for (double **q : {&sp.Hval, &sp.Jval, &sp.band, &sp.brhs, &sp.Hb0, &sp.Jb0, &sp.bD, &sp.bL, &sp.bU,
-                     &sp.bDinv, &sp.bF, &sp.bX})
+                     &sp.bDinv, &sp.bF, &sp.bX, &sp.brhs0, &sp.bres, &sp.bsol})
     if (*q) {
       (void)hipFree(*q);
       *q = nullptr;
@@ -956,6 +1029,13 @@ int pgf_sparse_set_pattern(pgf_handle h, int bw, const int *pos, int nnzH, const
   HIPCHK(h, dalloc(&sp.Jval, (size_t)nnzJ));
   HIPCHK(h, dalloc(&sp.band, (size_t)(N + 1) * sp.ldb));
   HIPCHK(h, dalloc(&sp.brhs, (size_t)N + 1));
+  HIPCHK(h, dalloc(&sp.brhs0, (size_t)N + 1));
+  HIPCHK(h, dalloc(&sp.bres, (size_t)N + 1));
+  HIPCHK(h, dalloc(&sp.bsol, (size_t)N + 1));
+  if (!sp.bred) {
+    HIPCHK(h, hipMalloc((void **)&sp.bred, 4 * sizeof(unsigned long long)));
+    HIPCHK(h, hipMemset(sp.bred, 0, 4 * sizeof(unsigned long long)));
+  }
   HIPCHK(h, dalloc(&sp.Hb0, (size_t)n + 1));
   HIPCHK(h, dalloc(&sp.Jb0, (size_t)m + 1));
   {

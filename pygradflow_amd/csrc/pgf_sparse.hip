@@ -387,8 +387,13 @@ void sp_launch_step_update(hipStream_t s, const SparseDev &sp, int n, int m, dou
 __global__ __launch_bounds__(64) void k_bcr_extract(const double *__restrict__ band, int ldb, int bw,
                                                     const double *__restrict__ rhs, int N, int nb,
                                                     double *__restrict__ D, double *__restrict__ L,
-                                                    double *__restrict__ U, double *__restrict__ F) {
+                                                    double *__restrict__ U, double *__restrict__ F,
+                                                    double *__restrict__ rhs0,
+                                                    unsigned long long *__restrict__ rsmax) {
   const int i = blockIdx.x, lane = threadIdx.x;
+  // accuracy guard (k_band_residual): the right-hand side survives the solve in rhs0
+  if (rhs0 && lane < 8 && i * 8 + lane < N) rhs0[i * 8 + lane] = rhs[i * 8 + lane];
+  if (rsmax && i == 0 && lane < 2) rsmax[lane] = 0ull;
   const int r = lane >> 3, c = lane & 7;
   const int gr = i * 8 + r, gc = i * 8 + c;
   // diagonal block, symmetric fill
@@ -828,14 +833,73 @@ __global__ void k_bcr_scatter(const double *__restrict__ X, double *__restrict__
   if (i < N) out[i] = X[i];
 }
 
+// Accuracy guard of the banded path: r = rhs0 - K x with K read from the assembled band (cyclic
+// reduction leaves it intact; lower band, row i holds K[i][i - d] at [i][d]), max |r| and
+// max |rhs0| as bit patterns (non-negative doubles order like integers) through atomicMax.
+__global__ __launch_bounds__(256) void k_band_residual(const double *__restrict__ band, int ldb, int bw,
+                                                       int N, const double *__restrict__ x,
+                                                       const double *__restrict__ rhs0,
+                                                       double *__restrict__ r,
+                                                       unsigned long long *__restrict__ rsmax) {
+  __shared__ double pr[4], pb[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double ar = 0.0, ab = 0.0;
+  if (i < N) {
+    double acc = rhs0[i];
+    ab = fabs(acc);
+    const double *row = band + (int64_t)i * ldb;
+    for (int d = 0; d <= bw && d <= i; ++d) acc = fma(-row[d], x[i - d], acc);
+    for (int d = 1; d <= bw && i + d < N; ++d) acc = fma(-band[(int64_t)(i + d) * ldb + d], x[i + d], acc);
+    r[i] = acc;
+    ar = (acc == acc) ? fabs(acc) : __builtin_huge_val();
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    ar = fmax(ar, __shfl_down(ar, off));
+    ab = fmax(ab, __shfl_down(ab, off));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    pr[threadIdx.x >> 6] = ar;
+    pb[threadIdx.x >> 6] = ab;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicMax(&rsmax[0], (unsigned long long)__double_as_longlong(fmax(fmax(pr[0], pr[1]), fmax(pr[2], pr[3]))));
+    atomicMax(&rsmax[1], (unsigned long long)__double_as_longlong(fmax(fmax(pb[0], pb[1]), fmax(pb[2], pb[3]))));
+  }
+}
+
+__global__ void k_band_reset_max(unsigned long long *rsmax) {
+  if (threadIdx.x < 2) rsmax[threadIdx.x] = 0ull;
+}
+
+void sp_launch_band_residual(hipStream_t s, const SparseDev &sp, int N, bool reset) {
+  if (N == 0) return;
+  if (reset) hipLaunchKernelGGL(k_band_reset_max, dim3(1), dim3(64), 0, s, sp.bred);
+  hipLaunchKernelGGL(k_band_residual, g1(N), dim3(256), 0, s, sp.band, sp.ldb, sp.bw, N, sp.brhs, sp.brhs0,
+                     sp.bres, sp.bred);
+}
+
+// x = saved + correction (refinement step of the guard)
+__global__ void k_band_axpy(int N, const double *__restrict__ a, double *__restrict__ x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) x[i] += a[i];
+}
+void sp_launch_band_axpy(hipStream_t s, int N, const double *a, double *x) {
+  if (N) hipLaunchKernelGGL(k_band_axpy, g1(N), dim3(256), 0, s, N, a, x);
+}
+
 // Solve the banded system in sp.band / sp.brhs by block cyclic reduction; the solution
 // replaces sp.brhs.  flags[0] zero pivot, flags[1] negative pivots.
-void sp_launch_bcr_solve(hipStream_t s, const SparseDev &sp, int N, int *flags) {
+// guard: keep the right-hand side and finish with the residual of the solution (bres, bred);
+// a correction solve of the refinement runs without.
+void sp_launch_bcr_solve(hipStream_t s, const SparseDev &sp, int N, int *flags, bool guard) {
   (void)hipMemsetAsync(flags, 0, 4 * sizeof(int), s);
   if (N == 0) return;
   const int nb = (N + 7) / 8;
   hipLaunchKernelGGL(k_bcr_extract, dim3(nb), dim3(64), 0, s, sp.band, sp.ldb, sp.bw, sp.brhs, N, nb,
-                     sp.bD, sp.bL, sp.bU, sp.bF);
+                     sp.bD, sp.bL, sp.bU, sp.bF, guard ? sp.brhs0 : nullptr,
+                     guard ? sp.bred : nullptr);
   // levels with many blocks: one workgroup per block; from the first level with at most
   // BCR_TAIL_BLOCKS blocks left: everything in one workgroup, in LDS
   // PGF_BCR_FUSED=0: separate invert / reduce launches per level
@@ -903,4 +967,5 @@ void sp_launch_bcr_solve(hipStream_t s, const SparseDev &sp, int N, int *flags) 
                          Fp(lev[q].set), sp.bX, nb, bs, bs, 2 * bs);
   }
   hipLaunchKernelGGL(k_bcr_scatter, g1(N), dim3(256), 0, s, sp.bX, sp.brhs, N);
+  if (guard) sp_launch_band_residual(s, sp, N, false);
 }

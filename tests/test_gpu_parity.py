@@ -949,6 +949,54 @@ def test_unstable_pivot_is_refined_or_handed_to_the_pivoted_lu(pgf, eps, expect)
     dn.close()
 
 
+def test_banded_unstable_pivot_is_refined(pgf):
+    """Accuracy guard of the banded path: block cyclic reduction inverts its 8 x 8 pivot blocks
+    without pivoting.  A tiny diagonal entry at the head of a block (here: at the head of the
+    band in either direction the bandwidth-reducing permutation may take) gives element growth
+    1e9 in a well-conditioned matrix; the residual check (K read from the intact band) notices
+    and refinement with the same reduction repairs the step."""
+    import scipy.sparse as sps
+    from pygradflow_amd import problems
+
+    n, eps = 200, 1e-9
+    rng = np.random.default_rng(3)
+    d = 2.5 + rng.uniform(0.0, 0.5, n)
+    # (first entry of a block that the FIRST reduction level inverts as it stands: an odd block)
+    d[8] = d[15] = -1.0 + eps  # lambda = 1: K[8, 8] = K[15, 15] = eps
+    e = np.ones(n - 1)
+    H = sps.diags([e, d, e], [-1, 0, 1], format="csr")
+    K = H.toarray() + np.eye(n)
+    assert np.linalg.cond(K) < 1e4
+    prob = problems.LinearQuadraticProblem(H, rng.standard_normal(n), sps.csr_matrix((0, n)), np.zeros(0),
+                                           np.full(n, -np.inf), np.full(n, np.inf))
+    prob.pgf_force_band = True
+    params = pgf.Params(newton_type="Full")
+    it = pgf.Iterate(prob, params, np.zeros(n), np.zeros(0))
+    sv = pgf.HipStepSolver(prob, params, it, 1.0, 1.0)
+    assert sv.sparse
+    sv.update_active_set(np.zeros(n, dtype=bool))
+    sv.update_derivs(it)
+    before = sv.refinement_stats()
+    res = sv.solve(it)
+    after = sv.refinement_stats()
+    F = sv.func.value_at(it, 1.0, np.zeros(n, dtype=bool))
+    s = np.linalg.solve(K, F)
+    assert after[0] > before[0], "the guard did not refine"
+    assert after[2] <= 1e-11
+    assert G.rel_err(res.dx, s) <= 1e-9
+    # the LinearSolver view of the banded factor is guarded as well
+    rhs = np.arange(1.0, n + 1.0)
+    assert G.rel_err(sv.solver.solve(rhs), np.linalg.solve(K, rhs)) <= 1e-9
+    sv.close()
+    # device-resident driver: same route
+    dn = pgf.DeviceNewton(prob, "Full", np.zeros(n), np.zeros(0), 1.0, 1.0)
+    assert dn.sparse
+    dn.step()
+    x, _ = dn.point()
+    assert G.rel_err(x, -s) <= 1e-9
+    dn.close()
+
+
 def test_in_place_modified_problem_is_uploaded_again(pgf):
     """HBM residency of constant H, J is keyed on the problem object AND a content fingerprint
     (ADVICE r1): modifying Q in place must not reuse the stale device copy."""
