@@ -1483,6 +1483,9 @@ int pgf_batch_create(const pgf_handle *handles, int count, pgf_batch *out) {
     t.LinvT = h->fac.LinvT;
     t.flags = h->fac.flags;
     t.hctl = h->fac.hctl;
+    t.xpub = h->fac.xpub;
+    t.cctl = h->fac.chain + 2 * h->fac.chain_stride;
+    t.capblk = h->fac.chain_stride;
     // the batch owns the device-side state of the handle from here on
     h->mask_set = false;
     h->eval_fresh = false;
@@ -1780,7 +1783,14 @@ int pgf_batch_sync(pgf_batch b, int *status, int *n_neg, double *diff) {
     // bit 1: the instance's chain helpers failed a hand-over check (kb_step_final): the step is
     // reported like a failed factorisation -- the controllers reject and repeat it -- and the
     // helpers are off from here on
-    if (b->h_flags[3 * i] & 2) ldlt_chain_helpers_off();
+    if (b->h_flags[3 * i] & 2) {
+      // (or one of its chained solves: those go off too, and the publication halves of the
+      // instance's handle get their sentinels back)
+      ldlt_chain_helpers_off();
+      ldlt_chain_set_enabled(false);
+      DenseLdlt &f = b->hs[i]->fac;
+      (void)hipMemsetAsync(f.xpub, 0xff, 2 * (size_t)f.chain_stride * 64 * sizeof(double), b->stream);
+    }
     all_ok = all_ok && !bad;
     if (status) status[i] = bad ? PGF_SINGULAR : PGF_OK;
     if (n_neg) n_neg[i] = b->h_flags[3 * i + 1];

@@ -43,7 +43,7 @@ struct DenseLdlt {
   // xpub: two halves of S * 64 published solution entries (sentinel = all bits set)
   int *chain = nullptr;
   double *xpub = nullptr;
-  int chain_stride = 0, chain_epoch = 0;
+  int chain_stride = 0;
   int *hctl = nullptr;      // stamps between the diagonal chain and its helper workgroups
   int *h_flags = nullptr;   // pinned host mirror ([3]: status word of the chained solves)
   hipStream_t stream = nullptr;
@@ -128,6 +128,11 @@ struct BInst {
   double *dvec, *dinv, *zwork, *Linv, *LinvT;
   int *flags;
   int *hctl;  // stamps between the instance's chain and its helper workgroups (small batches)
+  // chained triangular solves: both publication halves (capblk * 64 entries each) and the
+  // control words [0] XCC slot, [1] status, [2] solve counter of the instance's handle
+  double *xpub;
+  int *cctl;
+  int capblk;
 };
 
 struct BatchScalars {
@@ -193,6 +198,7 @@ void ldlt_batch_launch_chain_update(hipStream_t s, const BInst *tab, int B, int 
 void ldlt_batch_launch_trsm(hipStream_t s, const BInst *tab, int B, int per, int m, int wbuf, int c0);
 void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m, int OB,
                              PgfProfile *prof);
+bool ldlt_chain_enabled();  // chained solves requested (PGF_TRSV_CHAIN) and not switched off
 void ldlt_batch_solve_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m,
                             bool any_unfactored_solve);
 

@@ -969,7 +969,9 @@ __global__ __launch_bounds__(256) void kb_step_final(const BInst *__restrict__ t
   b_final_reduce(I.red, nb, diff_out + blockIdx.z, 1);
   if (threadIdx.x == 0) {
     // bit 0: zero / non-finite pivot; bit 1: the chain's helper workgroups failed a check
-    const int bad = (I.flags[0] ? 1 : 0) | (I.flags[2] ? 2 : 0);
+    // (a chained solve of the instance that failed its own checks counts like the helpers)
+    const int bad = (I.flags[0] ? 1 : 0) | ((I.flags[2] || I.cctl[1]) ? 2 : 0);
+    I.cctl[1] = 0;
     flags_out[3 * blockIdx.z] = bad;
     flags_out[3 * blockIdx.z + 1] = I.flags[1];
     flags_out[3 * blockIdx.z + 2] = I.counts[0];

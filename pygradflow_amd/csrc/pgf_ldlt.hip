@@ -611,18 +611,22 @@ __device__ __forceinline__ void chain_reset_other(double *other, int capblk, int
 }
 
 // backward: L^T x = z.  x_b = inv(L_bb)^T (z_b - sum_{a > b} L_ab^T x_a).  In place (x == z) ok.
-__global__ __launch_bounds__(256) void k_trsv_bwd_chain(const double *__restrict__ K, int64_t ldk,
-                                                        const double *__restrict__ Linv,
-                                                        const double *z, double *x, int N,
-                                                        double *__restrict__ xpub,
-                                                        double *__restrict__ xother, int capblk,
-                                                        int epoch, int *__restrict__ ctl) {
-  if (blockIdx.x & 7) return;
+// w: the worker's place in the chain (worker 0 solves the last block); xpub2: both publication
+// halves (capblk * 64 entries each); ctl: [0] XCC slot, [1] status, [2] the handle's solve
+// counter -- kept on the DEVICE, so that single-instance and batched solves of a pooled handle
+// agree on which half is clean: every worker reads it when it starts, the worker that ends the
+// chain (and therefore runs after every other worker has read it) advances it.
+__device__ __forceinline__ void chain_bwd_body(const double *__restrict__ K, int64_t ldk,
+                                               const double *__restrict__ Linv, const double *z,
+                                               double *x, int N, double *xpub2, int capblk,
+                                               int *__restrict__ ctl, int w) {
+  const int epoch = ctl[2] + 1;
+  double *xpub = xpub2 + (size_t)(epoch & 1) * capblk * 64;
+  double *xother = xpub2 + (size_t)((epoch + 1) & 1) * capblk * 64;
   chain_check_xcc(epoch, ctl);
   __shared__ double part[4][64];
   __shared__ double rs[64];
   const int nblk = (N + 63) / 64;
-  const int w = (int)(blockIdx.x >> 3);
   const int b = nblk - 1 - w;  // last block first
   const int b0 = b * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -687,22 +691,31 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_chain(const double *__restrict
       xpub[b0 + lane] = xv;
       x[b0 + lane] = xv;
     }
+    if (b == 0 && lane == 0) ctl[2] = epoch;  // end of the chain: every worker has read it
   }
 }
 
-// forward: L y = z.  y_b = inv(L_bb) (z_b - sum_{a < b} L_ba y_a).  In place ok.
-__global__ __launch_bounds__(256, 3) void k_trsv_fwd_chain(const double *__restrict__ K, int64_t ldk,
-                                                        const double *__restrict__ LinvT,
+__global__ __launch_bounds__(256) void k_trsv_bwd_chain(const double *__restrict__ K, int64_t ldk,
+                                                        const double *__restrict__ Linv,
                                                         const double *z, double *x, int N,
-                                                        double *__restrict__ xpub,
-                                                        double *__restrict__ xother, int capblk,
-                                                        int epoch, int *__restrict__ ctl) {
+                                                        double *xpub2, int capblk,
+                                                        int *__restrict__ ctl) {
   if (blockIdx.x & 7) return;
+  chain_bwd_body(K, ldk, Linv, z, x, N, xpub2, capblk, ctl, (int)(blockIdx.x >> 3));
+}
+
+// forward: L y = z.  y_b = inv(L_bb) (z_b - sum_{a < b} L_ba y_a).  In place ok.
+__device__ __forceinline__ void chain_fwd_body(const double *__restrict__ K, int64_t ldk,
+                                               const double *__restrict__ LinvT, const double *z,
+                                               double *x, int N, double *xpub2, int capblk,
+                                               int *__restrict__ ctl, int b) {
+  const int epoch = ctl[2] + 1;
+  double *xpub = xpub2 + (size_t)(epoch & 1) * capblk * 64;
+  double *xother = xpub2 + (size_t)((epoch + 1) & 1) * capblk * 64;
   chain_check_xcc(epoch, ctl);
   __shared__ double part[4][64];
   __shared__ double rs[64];
-  const int nblk = (N + 63) / 64;
-  const int b = (int)(blockIdx.x >> 3);  // first block first
+  const int nblk = (N + 63) / 64;  // b: first block first
   const int b0 = b * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   chain_reset_other(xother, capblk, b, nblk);
@@ -810,7 +823,17 @@ __global__ __launch_bounds__(256, 3) void k_trsv_fwd_chain(const double *__restr
       xpub[b0 + lane] = xv;
       x[b0 + lane] = xv;
     }
+    if (b == nblk - 1 && lane == 0) ctl[2] = epoch;  // end of the chain
   }
+}
+
+__global__ __launch_bounds__(256, 3) void k_trsv_fwd_chain(const double *__restrict__ K, int64_t ldk,
+                                                           const double *__restrict__ LinvT,
+                                                           const double *z, double *x, int N,
+                                                           double *xpub2, int capblk,
+                                                           int *__restrict__ ctl) {
+  if (blockIdx.x & 7) return;
+  chain_fwd_body(K, ldk, LinvT, z, x, N, xpub2, capblk, ctl, (int)(blockIdx.x >> 3));
 }
 
 // ------------------------------------------------------------------ batched variants
@@ -1478,6 +1501,7 @@ static bool use_chain() {
 }
 
 void ldlt_chain_set_enabled(bool on) { g_chain_off = !on; }
+bool ldlt_chain_enabled() { return use_chain(); }
 
 // after a host synchronisation of f.stream: did a chained solve since the last check fail its
 // own checks?  (bit 0: a wait timed out, bit 1: workers on different XCDs)
@@ -1517,11 +1541,8 @@ hipError_t ldlt_backsolve_async(DenseLdlt &f, const double *w, double *sol) {
   if (N == 0) return hipSuccess;
   if (use_chain()) {
     const int nblk = (N + 63) / 64;
-    const int ep = ++f.chain_epoch;
-    const size_t half = (size_t)f.chain_stride * 64;
     hipLaunchKernelGGL(k_trsv_bwd_chain, dim3(8 * nblk), dim3(256), 0, s, f.K, f.ldk, f.Linv, w, sol,
-                       N, f.xpub + (ep & 1) * half, f.xpub + ((ep + 1) & 1) * half, f.chain_stride,
-                       ep, f.chain + 2 * f.chain_stride);
+                       N, f.xpub, f.chain_stride, f.chain + 2 * f.chain_stride);
     return chain_report(f, sol);
   }
   hipLaunchKernelGGL(k_vec_copy_strided, dim3((N + 255) / 256), dim3(256), 0, s, f.zwork, w, N);
@@ -1542,11 +1563,8 @@ hipError_t ldlt_solve_async(DenseLdlt &f, const double *rhs, double *sol) {
   // forward: L y = rhs  (y lands in sol)
   if (use_chain()) {
     const int nblk = (N + 63) / 64;
-    const int ep = ++f.chain_epoch;
-    const size_t half = (size_t)f.chain_stride * 64;
     hipLaunchKernelGGL(k_trsv_fwd_chain, dim3(8 * nblk), dim3(256), 0, s, f.K, f.ldk, f.LinvT, rhs,
-                       sol, N, f.xpub + (ep & 1) * half, f.xpub + ((ep + 1) & 1) * half,
-                       f.chain_stride, ep, f.chain + 2 * f.chain_stride);
+                       sol, N, f.xpub, f.chain_stride, f.chain + 2 * f.chain_stride);
   } else {
     hipLaunchKernelGGL(k_vec_copy_strided, dim3((N + 255) / 256), dim3(256), 0, s, f.zwork, rhs, N);
     for (int c0 = 0; c0 < N; c0 += 256) {
@@ -1666,10 +1684,50 @@ void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, i
     hipLaunchKernelGGL(kb_inv_diag_blocks, dim3((Nmax + 63) / 64, 1, B), dim3(64), 0, s, tab, m);
 }
 
+// Chained solves of a batch: the single-instance chain bodies, instance i on XCD i % 8 (ids
+// 8 q + x: q walks the instances of residue class x one after the other, nwmax workers each, so
+// that a worker only ever waits for workers with smaller ids).  Every block of L is read once
+// -- the per-super-block kernels re-solve the 256-row super-block in every workgroup -- and
+// the instances' chains overlap: 256 instances of N = 1280: 0.9 -> ~0.2 ms per batched step.
+__global__ __launch_bounds__(256) void kb_trsv_bwd_chain(const BInst *__restrict__ tab, int B, int m,
+                                                         int nwmax) {
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int inst = xcd + 8 * (q / nwmax), w = q % nwmax;
+  if (inst >= B) return;
+  const BInst &I = tab[inst];
+  if (I.ctl[3]) return;
+  const int N = I.counts[0] + m;
+  if (w >= (N + 63) / 64) return;
+  chain_bwd_body(I.K, I.ldk, I.Linv, I.zwork, I.sol, N, I.xpub, I.capblk, I.cctl, w);
+}
+
+__global__ __launch_bounds__(256, 3) void kb_trsv_fwd_chain(const BInst *__restrict__ tab, int B,
+                                                            int m, int nwmax) {
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int inst = xcd + 8 * (q / nwmax), w = q % nwmax;
+  if (inst >= B) return;
+  const BInst &I = tab[inst];
+  if (I.ctl[0] != 0 || I.ctl[3]) return;
+  const int N = I.counts[0] + m;
+  if (w >= (N + 63) / 64) return;
+  chain_fwd_body(I.K, I.ldk, I.LinvT, I.zwork, I.sol, N, I.xpub, I.capblk, I.cctl, w);
+}
+
 void ldlt_batch_solve_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m,
                             bool any_unfactored_solve) {
   if (Nmax <= 0 || B <= 0) return;
   const dim3 gv((Nmax + 255) / 256, 1, B);
+  if (use_chain()) {
+    const int nwmax = (Nmax + 63) / 64;
+    const dim3 gc(8 * ((B + 7) / 8) * nwmax);
+    if (any_unfactored_solve) {
+      hipLaunchKernelGGL(kb_solve_prep_fwd, gv, dim3(256), 0, s, tab, m);
+      hipLaunchKernelGGL(kb_trsv_fwd_chain, gc, dim3(256), 0, s, tab, B, m, nwmax);
+    }
+    hipLaunchKernelGGL(kb_solve_prep_bwd, gv, dim3(256), 0, s, tab, m);
+    hipLaunchKernelGGL(kb_trsv_bwd_chain, gc, dim3(256), 0, s, tab, B, m, nwmax);
+    return;
+  }
   if (any_unfactored_solve) {
     hipLaunchKernelGGL(kb_solve_prep_fwd, gv, dim3(256), 0, s, tab, m);
     for (int c0 = 0; c0 < Nmax; c0 += 256) {

@@ -427,14 +427,17 @@ __global__ __launch_bounds__(64) void k_bcr_extract(const double *__restrict__ b
 __device__ __forceinline__ int gj_inverse8(double *M, int lane, int *bad) {
   const int r = lane >> 3, c = lane & 7;
   int neg = 0;
+  double mrc = M[lane];  // own entry: stays in a register between the steps
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const double p = M[k * 8 + k];
     const bool isbad = (p == 0.0) || !(fabs(p) <= 1.79e308);
     *bad |= isbad ? 1 : 0;
     neg += (p < 0.0) ? 1 : 0;
-    const double d = isbad ? 0.0 : 1.0 / p;
-    const double mrk = M[r * 8 + k], mkc = M[k * 8 + c], mrc = M[lane];
+    // v_rcp_f64 + two Newton steps (full precision) instead of the ~30-instruction IEEE
+    // division: eight of them sat on every block operation's dependent chain
+    const double d = isbad ? 0.0 : recip2(p);
+    const double mrk = M[r * 8 + k], mkc = M[k * 8 + c];
     double v;
     if (r == k && c == k)
       v = d;
@@ -445,6 +448,7 @@ __device__ __forceinline__ int gj_inverse8(double *M, int lane, int *bad) {
     else
       v = fma(-mrk * d, mkc, mrc);
     M[lane] = v;  // all lanes have read before any lane writes (one wavefront, lockstep)
+    mrc = v;
   }
   return neg;
 }

@@ -949,7 +949,8 @@ def test_unstable_pivot_is_refined_or_handed_to_the_pivoted_lu(pgf, eps, expect)
     dn.close()
 
 
-def test_banded_unstable_pivot_is_refined(pgf):
+@pytest.mark.parametrize("n", [200, 2008])  # 2008: 251 blocks, the chunked reduction
+def test_banded_unstable_pivot_is_refined(pgf, n):
     """Accuracy guard of the banded path: block cyclic reduction inverts its 8 x 8 pivot blocks
     without pivoting.  A tiny diagonal entry at the head of a block (here: at the head of the
     band in either direction the bandwidth-reducing permutation may take) gives element growth
@@ -958,7 +959,7 @@ def test_banded_unstable_pivot_is_refined(pgf):
     import scipy.sparse as sps
     from pygradflow_amd import problems
 
-    n, eps = 200, 1e-9
+    eps = 1e-9
     rng = np.random.default_rng(3)
     d = 2.5 + rng.uniform(0.0, 0.5, n)
     # (first entry of a block that the FIRST reduction level inverts as it stands: an odd block)

@@ -32,6 +32,28 @@ BATCH_VARIANTS = {
 }
 
 
+BAND_VARIANTS = {
+    "paired_levels": {},                              # default: two levels per launch where launch-bound
+    "one_level_per_launch": {"PGF_BCR_PAIRS": "0"},
+    "separate_invert_reduce": {"PGF_BCR_FUSED": "0"},
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(BAND_VARIANTS))
+def test_banded_schedule_variant_matches_oracle(gpu_available, name):
+    """tests/check_band.py: banded OCP and tridiagonal box QP (churning mask) against the CPU
+    oracle under each cyclic-reduction schedule."""
+    if not gpu_available:
+        pytest.skip("needs a GPU")
+    env = dict(os.environ)
+    env.update(BAND_VARIANTS[name])
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tests", "check_band.py")], env=env,
+                         cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "band ok" in out.stdout
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(BATCH_VARIANTS))
 def test_batched_schedule_variant_matches_one_by_one(gpu_available, name):
