@@ -182,18 +182,19 @@ __device__ __forceinline__ void b_reduced_rhs(int n, int m, int nI, int nA, doub
 // in H / J is looked up once per lane.  One row per workgroup was dispatch-bound in the
 // batched step (1.6 M workgroups).
 #define ASM_ROWS 8
+template <int ROWS = ASM_ROWS>
 __device__ __forceinline__ void b_assemble_kkt(double *__restrict__ K, int64_t ldk,
                                                const double *__restrict__ H, int64_t ldh,
                                                const double *__restrict__ J, int64_t ldj,
                                                const int *__restrict__ idxI, int nI, int m,
                                                double lamb, double delta) {
   const int N = nI + m;
-  const int i0 = blockIdx.y * ASM_ROWS;
+  const int i0 = blockIdx.y * ROWS;
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= N || j > i0 + ASM_ROWS - 1) return;
+  if (j >= N || j > i0 + ROWS - 1) return;
   const int gj = (j < nI) ? idxI[j] : 0;
 #pragma unroll
-  for (int r = 0; r < ASM_ROWS; ++r) {
+  for (int r = 0; r < ROWS; ++r) {
     const int i = i0 + r;
     if (i >= N) break;
     if (j > i) continue;
@@ -924,19 +925,22 @@ __global__ __launch_bounds__(256) void kb_reduced_rhs(const BInst *__restrict__ 
 }
 
 // K (lower triangle) + the right-hand side in row N, only for instances that factorise
+// (KB_ASM_ROWS rows per workgroup: with 8, a batch of 256 instances of N = 1280 is 206 000
+// workgroups and the launch is bound by their dispatch)
+#define KB_ASM_ROWS 32
 __global__ __launch_bounds__(256) void kb_assemble(const BInst *__restrict__ tab, int m) {
   const BInst &I = tab[blockIdx.z];
   if (I.ctl[0] == 0) return;
   const double lamb = I.ps[BPS_LAMB], delta = I.ps[BPS_DELTA];
   const int nI = I.counts[0], N = nI + m;
-  const int i0 = blockIdx.y * ASM_ROWS;
+  const int i0 = blockIdx.y * KB_ASM_ROWS;
   if (i0 > N) return;
   if (i0 == 0 && blockIdx.x == 0 && threadIdx.x < 4) I.flags[threadIdx.x] = 0;
-  if (i0 <= N && N < i0 + ASM_ROWS) {  // this row block also holds row N: the rhs
+  if (i0 <= N && N < i0 + KB_ASM_ROWS) {  // this row block also holds row N: the rhs
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j < N) I.K[(int64_t)N * I.ldk + j] = I.rhs[j];
   }
-  b_assemble_kkt(I.K, I.ldk, I.H, I.ldh, I.J, I.ldj, I.idxI, nI, m, lamb, delta);
+  b_assemble_kkt<KB_ASM_ROWS>(I.K, I.ldk, I.H, I.ldh, I.J, I.ldj, I.idxI, nI, m, lamb, delta);
 }
 
 __global__ __launch_bounds__(256) void kb_step_update(const BInst *__restrict__ tab, int n,
@@ -1139,7 +1143,7 @@ void batch_launch_rhs_assemble(hipStream_t s, const BInst *tab, int B, const Bat
   if (!Nmax) return;
   hipLaunchKernelGGL(kb_residual, gb(Nmax, 256, B), dim3(256), 0, s, tab, n, m);
   hipLaunchKernelGGL(kb_reduced_rhs, gb(Nmax, 4, B), dim3(256), 0, s, tab, n, m);
-  hipLaunchKernelGGL(kb_assemble, dim3((Nmax + 255) / 256, Nmax / ASM_ROWS + 1, B), dim3(256), 0,
+  hipLaunchKernelGGL(kb_assemble, dim3((Nmax + 255) / 256, Nmax / KB_ASM_ROWS + 1, B), dim3(256), 0,
                      s, tab, m);
 }
 
