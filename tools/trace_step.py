@@ -15,7 +15,7 @@ asm = [i for i, r in enumerate(rows) if r[2].startswith("k_assemble_kkt")]
 a, b = asm[-2], asm[-1]
 t0 = rows[a][0]
 prev_end = rows[a - 1][1] if a else t0
-fact = ("k_chain_update", "k_diag_chain", "k_trsm_block", "k_update_diag", "k_ldlt_update", "k_update_jobs")
+fact = ("k_chain_update", "k_diag_chain", "k_trsm_ud", "k_trsm_block", "k_update_diag", "k_ldlt_update", "k_update_jobs")
 agg = {}
 gap_total = 0
 print(f"step = {(rows[b][0] - t0) / 1e3:.1f} us, {b - a} launches")
