@@ -67,6 +67,7 @@ struct pgf_solver {
   bool factor_clean = false;
   bool rs_skipped = false;
   bool sp_guarded = false;  // banded path: the last solve carried the residual check (k_band_residual)
+  double *h_bred = nullptr;  // pinned mirror of sp.bred
 };
 
 struct pgf_linsolver {
@@ -208,6 +209,7 @@ int pgf_destroy(pgf_handle h) {
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h->h_rs) (void)hipHostFree(h->h_rs);
+  if (h->h_bred) (void)hipHostFree(h->h_bred);
   lu_free(h->lu);
   if (h->h_counts) (void)hipHostFree(h->h_counts);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
@@ -636,11 +638,22 @@ static int refine_if_needed(pgf_handle h, bool swapped, bool with_step = true) {
 // reduction on the residual each -- and PGF_SINGULAR when the residual stays above refine_fail:
 // the step controller then rejects the step and doubles lambda, which is what makes the
 // matrix quasi-definite again (the reference's own recovery path, step_control.py:80-107).
+static double sparse_residual_rel(pgf_handle h) {
+  double r = 0.0, b = 0.0;
+  for (int i = 0; i < h->sp.nred; ++i) {
+    const double ri = h->h_bred[2 * i];
+    if (!(ri == ri) || !(ri <= 1.79e308)) return HUGE_VAL;
+    r = std::max(r, ri);
+    b = std::max(b, h->h_bred[2 * i + 1]);
+  }
+  return r / (b > 0.0 ? b : 1.0);
+}
+
 static int sparse_refine(pgf_handle h, bool swapped, bool with_step) {
   if (!h->refine_mode || !h->sp_guarded) return PGF_OK;
   const int Nf = h->n + h->m;
   if (Nf == 0) return PGF_OK;
-  double rel = residual_rel(h);
+  double rel = sparse_residual_rel(h);
   h->stat_last_rel = rel;
   if (rel <= h->refine_tol) return PGF_OK;
   hipStream_t s = h->stream;
@@ -656,8 +669,8 @@ static int sparse_refine(pgf_handle h, bool swapped, bool with_step) {
     HIPCHK(h, hipMemcpyAsync(sp.brhs, sp.bres, (size_t)Nf * sizeof(double), hipMemcpyDeviceToDevice, s));
     sp_launch_bcr_solve(s, sp, Nf, h->fac.flags, /*guard=*/false);
     sp_launch_band_axpy(s, Nf, sp.bsol, sp.brhs);
-    sp_launch_band_residual(s, sp, Nf, /*reset=*/true);
-    HIPCHK(h, hipMemcpyAsync(h->h_rs, sp.bred, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    sp_launch_band_residual(s, sp, Nf);
+    HIPCHK(h, hipMemcpyAsync(h->h_bred, sp.bred, (size_t)2 * sp.nred * sizeof(double), hipMemcpyDeviceToHost, s));
     if (with_step) {
       unswap();
       sp_launch_step_update(s, sp, h->n, h->m, h->fact, h->rho, h->x, h->y, h->lb, h->ub, h->F, h->dx,
@@ -668,7 +681,7 @@ static int sparse_refine(pgf_handle h, bool swapped, bool with_step) {
     }
     HIPCHK(h, hipStreamSynchronize(s));
     ++h->stat_refined;
-    const double now = residual_rel(h);
+    const double now = sparse_residual_rel(h);
     if (!(now < rel)) {
       rel = now;
       break;
@@ -750,7 +763,8 @@ static int newton_core_async(pgf_handle h, bool *did_factor) {
       sp_launch_bcr_solve(s, h->sp, Nf, h->fac.flags, h->refine_mode != 0);
       h->sp_guarded = h->refine_mode != 0;
       if (h->sp_guarded)
-        (void)hipMemcpyAsync(h->h_rs, h->sp.bred, 2 * sizeof(double), hipMemcpyDeviceToHost, s);
+        (void)hipMemcpyAsync(h->h_bred, h->sp.bred, (size_t)2 * h->sp.nred * sizeof(double),
+                             hipMemcpyDeviceToHost, s);
       if (e0) {
         (void)hipEventRecord(e1, s);
         h->prof.update_spans.emplace_back(e0, e1);
@@ -886,7 +900,8 @@ int pgf_linear_solve(pgf_handle h, const double *rhs, int trans, double *sol) {
       sp_launch_bcr_solve(h->stream, h->sp, Nf, h->fac.flags, h->refine_mode != 0);
       h->sp_guarded = h->refine_mode != 0;
       if (h->sp_guarded)
-        HIPCHK(h, hipMemcpyAsync(h->h_rs, h->sp.bred, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->h_bred, h->sp.bred, (size_t)2 * h->sp.nred * sizeof(double),
+                                 hipMemcpyDeviceToHost, h->stream));
     } else {
       h->sp_guarded = false;
       if (!h->fac.factored) {
@@ -1032,10 +1047,17 @@ int pgf_sparse_set_pattern(pgf_handle h, int bw, const int *pos, int nnzH, const
   HIPCHK(h, dalloc(&sp.brhs0, (size_t)N + 1));
   HIPCHK(h, dalloc(&sp.bres, (size_t)N + 1));
   HIPCHK(h, dalloc(&sp.bsol, (size_t)N + 1));
-  if (!sp.bred) {
-    HIPCHK(h, hipMalloc((void **)&sp.bred, 4 * sizeof(unsigned long long)));
-    HIPCHK(h, hipMemset(sp.bred, 0, 4 * sizeof(unsigned long long)));
+  if (sp.bred) {
+    (void)hipFree(sp.bred);
+    sp.bred = nullptr;
   }
+  if (h->h_bred) {
+    (void)hipHostFree(h->h_bred);
+    h->h_bred = nullptr;
+  }
+  sp.nred = (N + 255) / 256;
+  HIPCHK(h, dalloc(&sp.bred, (size_t)2 * sp.nred));
+  HIPCHK(h, hipHostMalloc((void **)&h->h_bred, (size_t)2 * (sp.nred ? sp.nred : 1) * sizeof(double)));
   HIPCHK(h, dalloc(&sp.Hb0, (size_t)n + 1));
   HIPCHK(h, dalloc(&sp.Jb0, (size_t)m + 1));
   {

@@ -388,12 +388,10 @@ __global__ __launch_bounds__(64) void k_bcr_extract(const double *__restrict__ b
                                                     const double *__restrict__ rhs, int N, int nb,
                                                     double *__restrict__ D, double *__restrict__ L,
                                                     double *__restrict__ U, double *__restrict__ F,
-                                                    double *__restrict__ rhs0,
-                                                    unsigned long long *__restrict__ rsmax) {
+                                                    double *__restrict__ rhs0) {
   const int i = blockIdx.x, lane = threadIdx.x;
   // accuracy guard (k_band_residual): the right-hand side survives the solve in rhs0
   if (rhs0 && lane < 8 && i * 8 + lane < N) rhs0[i * 8 + lane] = rhs[i * 8 + lane];
-  if (rsmax && i == 0 && lane < 2) rsmax[lane] = 0ull;
   const int r = lane >> 3, c = lane & 7;
   const int gr = i * 8 + r, gc = i * 8 + c;
   // diagonal block, symmetric fill
@@ -839,21 +837,33 @@ __global__ void k_bcr_scatter(const double *__restrict__ X, double *__restrict__
 
 // Accuracy guard of the banded path: r = rhs0 - K x with K read from the assembled band (cyclic
 // reduction leaves it intact; lower band, row i holds K[i][i - d] at [i][d]), max |r| and
-// max |rhs0| as bit patterns (non-negative doubles order like integers) through atomicMax.
+// max |rhs0| per workgroup.
 __global__ __launch_bounds__(256) void k_band_residual(const double *__restrict__ band, int ldb, int bw,
                                                        int N, const double *__restrict__ x,
                                                        const double *__restrict__ rhs0,
                                                        double *__restrict__ r,
-                                                       unsigned long long *__restrict__ rsmax) {
+                                                       double *__restrict__ rsmax) {
+  // rows [i0, i0 + 256 + bw) of the band (contiguous in memory: coalesced) and x[i0 - bw,
+  // i0 + 256 + bw) staged in LDS: row i needs its own band row and, for the upper triangle, the
+  // rows i + 1 .. i + bw of its neighbours (bw <= 10, ldb <= 12)
+  __shared__ double bs[(256 + 10) * 12];
+  __shared__ double xs[256 + 20];
   __shared__ double pr[4], pb[4];
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i0 = blockIdx.x * 256, tid = threadIdx.x;
+  const int nrow = min(256 + bw, N - i0);
+  for (int p = tid; p < nrow * ldb; p += 256) bs[p] = band[(int64_t)i0 * ldb + p];
+  for (int p = tid; p < 256 + 2 * bw; p += 256) {
+    const int g = i0 - bw + p;
+    xs[p] = (g >= 0 && g < N) ? x[g] : 0.0;
+  }
+  __syncthreads();
+  const int i = i0 + tid;
   double ar = 0.0, ab = 0.0;
   if (i < N) {
     double acc = rhs0[i];
     ab = fabs(acc);
-    const double *row = band + (int64_t)i * ldb;
-    for (int d = 0; d <= bw && d <= i; ++d) acc = fma(-row[d], x[i - d], acc);
-    for (int d = 1; d <= bw && i + d < N; ++d) acc = fma(-band[(int64_t)(i + d) * ldb + d], x[i + d], acc);
+    for (int d = 0; d <= bw && d <= i; ++d) acc = fma(-bs[tid * ldb + d], xs[bw + tid - d], acc);
+    for (int d = 1; d <= bw && i + d < N; ++d) acc = fma(-bs[(tid + d) * ldb + d], xs[bw + tid + d], acc);
     r[i] = acc;
     ar = (acc == acc) ? fabs(acc) : __builtin_huge_val();
   }
@@ -867,19 +877,16 @@ __global__ __launch_bounds__(256) void k_band_residual(const double *__restrict_
     pb[threadIdx.x >> 6] = ab;
   }
   __syncthreads();
+  // one pair per workgroup, reduced on the host after the step's synchronisation (586 atomics on
+  // two words cost 14 us: same-address atomics serialise in L2)
   if (threadIdx.x == 0) {
-    atomicMax(&rsmax[0], (unsigned long long)__double_as_longlong(fmax(fmax(pr[0], pr[1]), fmax(pr[2], pr[3]))));
-    atomicMax(&rsmax[1], (unsigned long long)__double_as_longlong(fmax(fmax(pb[0], pb[1]), fmax(pb[2], pb[3]))));
+    rsmax[2 * blockIdx.x] = fmax(fmax(pr[0], pr[1]), fmax(pr[2], pr[3]));
+    rsmax[2 * blockIdx.x + 1] = fmax(fmax(pb[0], pb[1]), fmax(pb[2], pb[3]));
   }
 }
 
-__global__ void k_band_reset_max(unsigned long long *rsmax) {
-  if (threadIdx.x < 2) rsmax[threadIdx.x] = 0ull;
-}
-
-void sp_launch_band_residual(hipStream_t s, const SparseDev &sp, int N, bool reset) {
+void sp_launch_band_residual(hipStream_t s, const SparseDev &sp, int N) {
   if (N == 0) return;
-  if (reset) hipLaunchKernelGGL(k_band_reset_max, dim3(1), dim3(64), 0, s, sp.bred);
   hipLaunchKernelGGL(k_band_residual, g1(N), dim3(256), 0, s, sp.band, sp.ldb, sp.bw, N, sp.brhs, sp.brhs0,
                      sp.bres, sp.bred);
 }
@@ -902,8 +909,7 @@ void sp_launch_bcr_solve(hipStream_t s, const SparseDev &sp, int N, int *flags, 
   if (N == 0) return;
   const int nb = (N + 7) / 8;
   hipLaunchKernelGGL(k_bcr_extract, dim3(nb), dim3(64), 0, s, sp.band, sp.ldb, sp.bw, sp.brhs, N, nb,
-                     sp.bD, sp.bL, sp.bU, sp.bF, guard ? sp.brhs0 : nullptr,
-                     guard ? sp.bred : nullptr);
+                     sp.bD, sp.bL, sp.bU, sp.bF, guard ? sp.brhs0 : nullptr);
   // levels with many blocks: one workgroup per block; from the first level with at most
   // BCR_TAIL_BLOCKS blocks left: everything in one workgroup, in LDS
   // PGF_BCR_FUSED=0: separate invert / reduce launches per level
@@ -971,5 +977,5 @@ void sp_launch_bcr_solve(hipStream_t s, const SparseDev &sp, int N, int *flags, 
                          Fp(lev[q].set), sp.bX, nb, bs, bs, 2 * bs);
   }
   hipLaunchKernelGGL(k_bcr_scatter, g1(N), dim3(256), 0, s, sp.bX, sp.brhs, N);
-  if (guard) sp_launch_band_residual(s, sp, N, false);
+  if (guard) sp_launch_band_residual(s, sp, N);
 }
