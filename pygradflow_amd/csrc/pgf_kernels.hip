@@ -957,6 +957,59 @@ __global__ __launch_bounds__(256) void kb_step_update(const BInst *__restrict__ 
     I.y[i - n] = I.yn[i - n];
 }
 
+// Accuracy guard of the batched path.  The factor has overwritten the assembled matrix and a
+// full residual would read H and J of every instance again (3 GB for 256 instances, 7 % of the
+// step); element growth in an unpivoted LDL^T spoils the whole solution vector, so a SAMPLE of
+// the rows of r = rhs - K s tells just as well: KB_NSAMPLE rows spread over the reduced system,
+// K applied from H, J, the index list and the instance's lambda / delta, one wavefront per row.
+// max |r_sampled| > KB_RES_TOL max |rhs| sets flags[3]: the step is reported as failed
+// (kb_step_final), which every controller answers with a rejected step and a doubled lambda --
+// the reference's own recovery path (step_control.py:80-107) and what makes the matrix
+// quasi-definite again.
+#define KB_NSAMPLE 32
+#define KB_RES_TOL 1e-8
+__global__ __launch_bounds__(256) void kb_sample_residual(const BInst *__restrict__ tab, int m) {
+  // grid (KB_NSAMPLE / 4, 1, B): one sampled row per wavefront (a row is a chain of dependent
+  // gathers: 32 rows one after the other in one workgroup cost 0.1 ms per batched step)
+  const BInst &I = tab[blockIdx.z];
+  if (I.ctl[3]) return;
+  __shared__ double bmax[4];
+  const int nI = I.counts[0], N = nI + m;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double lamb = I.ps[BPS_LAMB], delta = I.ps[BPS_DELTA];
+  double rb = 0.0;
+  for (int j = tid; j < N; j += 256) rb = fmax(rb, fabs(I.rhs[j]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) rb = fmax(rb, __shfl_down(rb, off));
+  if (lane == 0) bmax[wave] = rb;
+  __syncthreads();
+  const double b = fmax(fmax(bmax[0], bmax[1]), fmax(bmax[2], bmax[3]));
+  const int ns = min(KB_NSAMPLE, N);
+  const int k = blockIdx.x * 4 + wave;
+  if (k >= ns) return;
+  const int i = (int)(((long long)k * N) / ns);
+  double acc = 0.0;
+  if (i < nI) {
+    const double *hrow = I.H + (int64_t)I.idxI[i] * I.ldh;
+    for (int j = lane; j < nI; j += 64) acc = fma(hrow[I.idxI[j]], I.sol[j], acc);
+    const double *jcol = I.J + I.idxI[i];
+    for (int r = lane; r < m; r += 64) acc = fma(jcol[(int64_t)r * I.ldj], I.sol[nI + r], acc);
+    if (lane == 0) acc = fma(lamb, I.sol[i], acc);
+  } else {
+    const double *jrow = I.J + (int64_t)(i - nI) * I.ldj;
+    for (int j = lane; j < nI; j += 64) acc = fma(jrow[I.idxI[j]], I.sol[j], acc);
+    if (lane == 0) acc = fma(-delta, I.sol[i], acc);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if (lane == 0) {
+    const double r = fabs(I.rhs[i] - acc);
+    // (flags[3] was cleared by kb_solve_prep_bwd of this step; set only on failure: no
+    // contention in the normal case)
+    if (!(r <= KB_RES_TOL * (b > 0.0 ? b : 1.0))) atomicOr(&I.flags[3], 1);
+  }
+}
+
 __global__ __launch_bounds__(256) void kb_step_final(const BInst *__restrict__ tab, int nb,
                                                      double *__restrict__ diff_out,
                                                      int *__restrict__ flags_out) {
@@ -974,7 +1027,8 @@ __global__ __launch_bounds__(256) void kb_step_final(const BInst *__restrict__ t
   if (threadIdx.x == 0) {
     // bit 0: zero / non-finite pivot; bit 1: the chain's helper workgroups failed a check
     // (a chained solve of the instance that failed its own checks counts like the helpers)
-    const int bad = (I.flags[0] ? 1 : 0) | ((I.flags[2] || I.cctl[1]) ? 2 : 0);
+    // bit 2: the sampled residual of the solve is too large (kb_sample_residual)
+    const int bad = (I.flags[0] ? 1 : 0) | ((I.flags[2] || I.cctl[1]) ? 2 : 0) | (I.flags[3] ? 4 : 0);
     I.cctl[1] = 0;
     flags_out[3 * blockIdx.z] = bad;
     flags_out[3 * blockIdx.z + 1] = I.flags[1];
@@ -1150,6 +1204,7 @@ void batch_launch_rhs_assemble(hipStream_t s, const BInst *tab, int B, const Bat
 void batch_launch_step_update(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc,
                               double *diff_out, int *flags_out) {
   const int nb = step_update_blocks(sc.n, sc.m);
+  hipLaunchKernelGGL(kb_sample_residual, dim3(KB_NSAMPLE / 4, 1, B), dim3(256), 0, s, tab, sc.m);
   if (nb)
     hipLaunchKernelGGL(kb_step_update, dim3(nb, 1, B), dim3(256), 0, s, tab, sc.n, sc.m);
   hipLaunchKernelGGL(kb_step_final, dim3(1, 1, B), dim3(256), 0, s, tab, nb, diff_out, flags_out);

@@ -1291,6 +1291,7 @@ __global__ void kb_solve_prep_bwd(const BInst *__restrict__ tab, int m) {
   if (I.ctl[3]) return;
   const int N = I.counts[0] + m;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) I.flags[3] = 0;  // the sampled residual check of this step (kb_sample_residual)
   if (i >= N) return;
   I.zwork[i] = I.ctl[0] ? I.K[(int64_t)N * I.ldk + i] : I.sol[i] * I.dinv[i];
 }

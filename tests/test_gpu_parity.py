@@ -998,6 +998,33 @@ def test_banded_unstable_pivot_is_refined(pgf, n):
     dn.close()
 
 
+def test_batched_unstable_pivot_fails_only_that_instance(pgf):
+    """Accuracy guard of the batched path: a sampled residual of every solve (the factor has
+    overwritten the matrix; element growth spoils all of the solution, so a sample of rows tells).
+    An instance whose unpivoted LDL^T meets a pivot of 1e-9 reports a failed step -- the
+    controllers reject it and double lambda -- while the other instances of the batch are
+    untouched and accurate."""
+    from pygradflow_amd.batched import BatchedDeviceNewton
+    from pygradflow_amd import problems
+
+    n, m, B, bad = 40, 8, 5, 2
+
+    def make(i):
+        return _tiny_pivot_qp(1e-9) if i == bad else problems.dense_qp(n, m, seed=30 + i)
+
+    bd = BatchedDeviceNewton(make, B, "Full", 1.0, 1.0)
+    st, nn, df = bd.step_local()
+    assert st[bad] != 0, "the unstable instance was not flagged"
+    ok = [i for i in range(B) if i != bad]
+    assert not st[ok].any()
+    x, y = bd.points()
+    for i in ok:
+        ref = O.NewtonOracle(make(i), "Full", np.zeros(n), np.zeros(m), 1.0, 1.0)
+        xn, yn, _ = ref.step(np.zeros(n), np.zeros(m))
+        assert G.rel_err(x[i], xn) <= TOL and G.rel_err(y[i], yn) <= TOL, i
+    bd.close()
+
+
 def test_in_place_modified_problem_is_uploaded_again(pgf):
     """HBM residency of constant H, J is keyed on the problem object AND a content fingerprint
     (ADVICE r1): modifying Q in place must not reuse the stale device copy."""
