@@ -421,7 +421,8 @@ def main():
                       "the factorisation's kernels run as separate launches with HIP events "
                       "around them; in the timed region the diagonal chain and the trailing "
                       "update share one launch (k_chain_update: same tile code, same job "
-                      "table); launches follow the lazy plan, so K-depth varies per tile"),
+                      "table; likewise k_trsm_block and k_update_diag are one launch there, "
+                      "k_trsm_ud); launches follow the lazy plan, so K-depth varies per tile"),
             )
             # the STEP against the FP64-MFMA roof -- algorithmic flops of one
             # Full Newton step (factor N^3/3, solves 2 N^2, residual 2 n^2 + 4 n m) x steps/s
