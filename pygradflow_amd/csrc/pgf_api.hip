@@ -218,7 +218,7 @@ int pgf_destroy(pgf_handle h) {
     SparseDev &sp = h->sp;
     void *sps[] = {sp.pos, sp.Hptr, sp.Hrow, sp.Hcol, sp.Hslot, sp.Jptr, sp.Jcol, sp.Jslot, sp.JTptr,
                    sp.JTrow, sp.JTmap, sp.Hval, sp.Jval, sp.band, sp.brhs, sp.Hb0, sp.Jb0,
-                   sp.bD, sp.bL, sp.bU, sp.bDinv, sp.bF, sp.bX, sp.bneg, sp.brhs0, sp.bres, sp.bsol,
+                   sp.bD, sp.bL, sp.bU, sp.bDinv, sp.bF, sp.bneg, sp.brhs0, sp.bres, sp.bsol,
                    sp.bred};
     for (void *q : sps)
       if (q) (void)hipFree(q);
@@ -1031,7 +1031,7 @@ int pgf_sparse_set_pattern(pgf_handle h, int bw, const int *pos, int nnzH, const
   if ((rc = up_new(h, &sp.JTrow, JTrow, (size_t)nnzJ))) return rc;
   if ((rc = up_new(h, &sp.JTmap, JTmap, (size_t)nnzJ))) return rc;
   for (double **q : {&sp.Hval, &sp.Jval, &sp.band, &sp.brhs, &sp.Hb0, &sp.Jb0, &sp.bD, &sp.bL, &sp.bU,
-                     &sp.bDinv, &sp.bF, &sp.bX, &sp.brhs0, &sp.bres, &sp.bsol})
+                     &sp.bDinv, &sp.bF, &sp.brhs0, &sp.bres, &sp.bsol})
     if (*q) {
       (void)hipFree(*q);
       *q = nullptr;
@@ -1043,7 +1043,7 @@ int pgf_sparse_set_pattern(pgf_handle h, int bw, const int *pos, int nnzH, const
   HIPCHK(h, dalloc(&sp.Hval, (size_t)nnzH));
   HIPCHK(h, dalloc(&sp.Jval, (size_t)nnzJ));
   HIPCHK(h, dalloc(&sp.band, (size_t)(N + 1) * sp.ldb));
-  HIPCHK(h, dalloc(&sp.brhs, (size_t)N + 1));
+  HIPCHK(h, dalloc(&sp.brhs, (size_t)N + 16));  // whole 8-row blocks: the cyclic reduction's X
   HIPCHK(h, dalloc(&sp.brhs0, (size_t)N + 1));
   HIPCHK(h, dalloc(&sp.bres, (size_t)N + 1));
   HIPCHK(h, dalloc(&sp.bsol, (size_t)N + 1));
@@ -1068,7 +1068,7 @@ int pgf_sparse_set_pattern(pgf_handle h, int bw, const int *pos, int nnzH, const
     HIPCHK(h, dalloc(&sp.bDinv, nbk * 64));
     HIPCHK(h, dalloc(&sp.bF, 2 * nbk * 8));
     sp.bstride = (int64_t)nbk;
-    HIPCHK(h, dalloc(&sp.bX, nbk * 8));
+    sp.bX = sp.brhs;  // the back-substitution writes the solution where the step update reads it
     HIPCHK(h, dalloc(&sp.bneg, nbk));
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1165,10 +1165,7 @@ static void qp_eval(pgf_handle h) {
   hipStream_t s = h->stream;
   if (h->sparse) {
     const SparseDev &sp = h->sp;
-    sp_launch_spmv(s, h->m, sp.Jptr, sp.Jcol, sp.Jval, h->x, h->b, -1.0, h->c);
-    launch_mult_vec(s, h->m, h->rho, h->c, h->y, h->w);
-    sp_launch_spmvT(s, h->n, sp.JTptr, sp.JTrow, sp.JTmap, sp.Jval, h->w, h->q, h->tmpn);
-    sp_launch_spmv(s, h->n, sp.Hptr, sp.Hcol, sp.Hval, h->x, h->tmpn, 1.0, h->g);
+    sp_launch_eval(s, sp, h->n, h->m, h->x, h->y, h->b, h->q, h->rho, h->c, h->w, h->g);
     h->eval_fresh = true;
     return;
   }

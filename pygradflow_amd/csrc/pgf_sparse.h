@@ -34,6 +34,9 @@ void sp_launch_spmv(hipStream_t s, int rows, const int *ptr, const int *col, con
                     const double *x, const double *add, double sgn, double *y);
 void sp_launch_spmvT(hipStream_t s, int cols, const int *tptr, const int *trow, const int *tmap,
                      const double *val, const double *w, const double *base, double *out);
+// c = J x - b ; w = rho c + y ; g = H x + (q + J' w)
+void sp_launch_eval(hipStream_t s, const SparseDev &sp, int n, int m, const double *x, const double *y,
+                    const double *b, const double *q, double rho, double *c, double *w, double *g);
 void sp_launch_assemble(hipStream_t s, const SparseDev &sp, int n, int m, const uint8_t *mask,
                         double lamb, double delta);
 void sp_launch_rhs(hipStream_t s, const SparseDev &sp, int n, int m, const uint8_t *mask,

@@ -43,6 +43,65 @@ __global__ void k_csc_spmvT(int cols, const int *__restrict__ tptr, const int *_
   out[j] = base[j] + acc;
 }
 
+// The evaluation of the device-resident sparse mode in two launches instead of four (the banded
+// path is bound by the number of its small dependent launches, not by their arithmetic):
+//   c = J x - b ; w = rho c + y                  (one lane per constraint row)
+//   g = H x + (q + J' w)                         (one lane per variable: row of H, column of J)
+// Operation order as in the separate kernels (k_csr_spmv, k_mult_vec, k_csc_spmvT): the active-set
+// mask computed from g is compared bit for bit.
+__global__ void k_sp_eval_c(int m, const int *__restrict__ ptr, const int *__restrict__ col,
+                            const double *__restrict__ val, const double *__restrict__ x,
+                            const double *__restrict__ b, double rho, const double *__restrict__ y,
+                            double *__restrict__ c, double *__restrict__ w) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= m) return;
+  double acc = 0.0;
+  for (int k = ptr[r]; k < ptr[r + 1]; ++k) acc = fma(val[k], x[col[k]], acc);
+  const double cr = acc + -1.0 * b[r];
+  c[r] = cr;
+  w[r] = rho * cr + y[r];
+}
+
+__global__ void k_sp_eval_g(int n, const int *__restrict__ hptr, const int *__restrict__ hcol,
+                            const double *__restrict__ hval, const int *__restrict__ tptr,
+                            const int *__restrict__ trow, const int *__restrict__ tmap,
+                            const double *__restrict__ jval, const double *__restrict__ x,
+                            const double *__restrict__ w, const double *__restrict__ q,
+                            double *__restrict__ g) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double at = 0.0;
+  for (int k = tptr[j]; k < tptr[j + 1]; ++k) at = fma(jval[tmap[k]], w[trow[k]], at);
+  const double base = q[j] + at;  // = tmpn[j] of the separate kernels
+  double acc = 0.0;
+  for (int k = hptr[j]; k < hptr[j + 1]; ++k) acc = fma(hval[k], x[hcol[k]], acc);
+  g[j] = acc + 1.0 * base;
+}
+
+// permuted right-hand side with the products H b0, J b0 formed on the fly (one launch for
+// k_csr_spmv x 2 + k_band_rhs)
+__global__ void k_band_rhs_fused(int n, int m, const uint8_t *__restrict__ mask,
+                                 const double *__restrict__ F, const double *__restrict__ b0full,
+                                 const int *__restrict__ hptr, const int *__restrict__ hcol,
+                                 const double *__restrict__ hval, const int *__restrict__ jptr,
+                                 const int *__restrict__ jcol, const double *__restrict__ jval,
+                                 double fact, const int *__restrict__ pos, double *__restrict__ brhs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n + m) return;
+  double v;
+  if (i < n) {
+    double acc = 0.0;
+    for (int k = hptr[i]; k < hptr[i + 1]; ++k) acc = fma(hval[k], b0full[hcol[k]], acc);
+    v = mask[i] ? b0full[i] : F[i] - acc;
+  } else {
+    const int r = i - n;
+    double acc = 0.0;
+    for (int k = jptr[r]; k < jptr[r + 1]; ++k) acc = fma(jval[k], b0full[jcol[k]], acc);
+    v = fact * F[i] - acc;
+  }
+  brhs[pos[i]] = v;
+}
+
 // ---------------------------------------------------------------- band assembly
 // diagonal: lamb (inactive variable), 1 (active variable), -delta (constraint)
 __global__ void k_band_set_diag(int n, int m, const int *__restrict__ pos,
@@ -315,6 +374,14 @@ void sp_launch_spmvT(hipStream_t s, int cols, const int *tptr, const int *trow, 
     hipLaunchKernelGGL(k_csc_spmvT, g1(cols), dim3(256), 0, s, cols, tptr, trow, tmap, val, w, base, out);
 }
 
+void sp_launch_eval(hipStream_t s, const SparseDev &sp, int n, int m, const double *x, const double *y,
+                    const double *b, const double *q, double rho, double *c, double *w, double *g) {
+  if (m) hipLaunchKernelGGL(k_sp_eval_c, g1(m), dim3(256), 0, s, m, sp.Jptr, sp.Jcol, sp.Jval, x, b, rho, y, c, w);
+  if (n)
+    hipLaunchKernelGGL(k_sp_eval_g, g1(n), dim3(256), 0, s, n, sp.Hptr, sp.Hcol, sp.Hval, sp.JTptr, sp.JTrow,
+                       sp.JTmap, sp.Jval, x, w, q, g);
+}
+
 void sp_launch_assemble(hipStream_t s, const SparseDev &sp, int n, int m, const uint8_t *mask,
                         double lamb, double delta) {
   const int N = n + m;
@@ -331,10 +398,11 @@ void sp_launch_assemble(hipStream_t s, const SparseDev &sp, int n, int m, const 
 
 void sp_launch_rhs(hipStream_t s, const SparseDev &sp, int n, int m, const uint8_t *mask,
                    const double *F, const double *b0full, double fact, double *Hb0, double *Jb0) {
-  sp_launch_spmv(s, n, sp.Hptr, sp.Hcol, sp.Hval, b0full, nullptr, 0.0, Hb0);
-  sp_launch_spmv(s, m, sp.Jptr, sp.Jcol, sp.Jval, b0full, nullptr, 0.0, Jb0);
-  hipLaunchKernelGGL(k_band_rhs, g1(n + m), dim3(256), 0, s, n, m, mask, F, b0full, Hb0, Jb0, fact,
-                     sp.pos, sp.brhs);
+  (void)Hb0;
+  (void)Jb0;
+  if (n + m)
+    hipLaunchKernelGGL(k_band_rhs_fused, g1(n + m), dim3(256), 0, s, n, m, mask, F, b0full, sp.Hptr, sp.Hcol,
+                       sp.Hval, sp.Jptr, sp.Jcol, sp.Jval, fact, sp.pos, sp.brhs);
 }
 
 void sp_launch_permute(hipStream_t s, const SparseDev &sp, int N, const double *in, double *out,
@@ -388,8 +456,10 @@ __global__ __launch_bounds__(64) void k_bcr_extract(const double *__restrict__ b
                                                     const double *__restrict__ rhs, int N, int nb,
                                                     double *__restrict__ D, double *__restrict__ L,
                                                     double *__restrict__ U, double *__restrict__ F,
-                                                    double *__restrict__ rhs0) {
+                                                    double *__restrict__ rhs0,
+                                                    int *__restrict__ flags) {
   const int i = blockIdx.x, lane = threadIdx.x;
+  if (i == 0 && lane < 4) flags[lane] = 0;  // (every kernel that sets them runs after this one)
   // accuracy guard (k_band_residual): the right-hand side survives the solve in rhs0
   if (rhs0 && lane < 8 && i * 8 + lane < N) rhs0[i * 8 + lane] = rhs[i * 8 + lane];
   const int r = lane >> 3, c = lane & 7;
@@ -905,11 +975,13 @@ void sp_launch_band_axpy(hipStream_t s, int N, const double *a, double *x) {
 // guard: keep the right-hand side and finish with the residual of the solution (bres, bred);
 // a correction solve of the refinement runs without.
 void sp_launch_bcr_solve(hipStream_t s, const SparseDev &sp, int N, int *flags, bool guard) {
-  (void)hipMemsetAsync(flags, 0, 4 * sizeof(int), s);
-  if (N == 0) return;
+  if (N == 0) {
+    (void)hipMemsetAsync(flags, 0, 4 * sizeof(int), s);
+    return;
+  }
   const int nb = (N + 7) / 8;
   hipLaunchKernelGGL(k_bcr_extract, dim3(nb), dim3(64), 0, s, sp.band, sp.ldb, sp.bw, sp.brhs, N, nb,
-                     sp.bD, sp.bL, sp.bU, sp.bF, guard ? sp.brhs0 : nullptr);
+                     sp.bD, sp.bL, sp.bU, sp.bF, guard ? sp.brhs0 : nullptr, flags);
   // levels with many blocks: one workgroup per block; from the first level with at most
   // BCR_TAIL_BLOCKS blocks left: everything in one workgroup, in LDS
   // PGF_BCR_FUSED=0: separate invert / reduce launches per level
@@ -976,6 +1048,6 @@ void sp_launch_bcr_solve(hipStream_t s, const SparseDev &sp, int N, int *flags, 
       hipLaunchKernelGGL(k_bcr_back, dim3(ne), dim3(64), 0, s, sp.bDinv, Lp(lev[q].set), Up(lev[q].set),
                          Fp(lev[q].set), sp.bX, nb, bs, bs, 2 * bs);
   }
-  hipLaunchKernelGGL(k_bcr_scatter, g1(N), dim3(256), 0, s, sp.bX, sp.brhs, N);
+  // (sp.bX IS sp.brhs: the back-substitution writes the solution where the caller reads it)
   if (guard) sp_launch_band_residual(s, sp, N);
 }
