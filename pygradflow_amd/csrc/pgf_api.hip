@@ -68,6 +68,7 @@ struct pgf_solver {
   bool rs_skipped = false;
   bool sp_guarded = false;  // banded path: the last solve carried the residual check (k_band_residual)
   double *h_bred = nullptr;  // pinned mirror of sp.bred
+  bool sp_stat_pending = false;  // a guarded banded step's status block is on its way to h_bred
 };
 
 struct pgf_linsolver {
@@ -511,7 +512,23 @@ static int factor_async(pgf_handle h, bool with_rhs) {
 static const char *k_helper_msg =
     "the dense factorisation failed its hand-over checks with and without helper workgroups";
 
+// a guarded banded step's status block (newton_core_async): after the stream has drained, the
+// pivot flags and the step length take their usual places
+static int sparse_status_sync(pgf_handle h) {
+  if (!h->sparse || !h->sp_stat_pending) return PGF_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->sp_stat_pending = false;
+  const int nr = h->sp.nred;
+  double sum = 0.0;
+  for (int i = 0; i < nr; ++i) sum += h->h_bred[2 * nr + i];
+  h->h_scal[0] = sqrt(sum);
+  for (int k = 0; k < 4; ++k) h->fac.h_flags[k] = (int)h->h_bred[3 * nr + k];
+  return PGF_OK;
+}
+
 static int factor_finish(pgf_handle h) {
+  int rcs;
+  if ((rcs = sparse_status_sync(h))) return rcs;
   hipError_t e;
   const int st = ldlt_finish(h->fac, &e);
   if (st < 0) return hip_fail(h, e, "factor");
@@ -669,7 +686,7 @@ static int sparse_refine(pgf_handle h, bool swapped, bool with_step) {
     HIPCHK(h, hipMemcpyAsync(sp.brhs, sp.bres, (size_t)Nf * sizeof(double), hipMemcpyDeviceToDevice, s));
     sp_launch_bcr_solve(s, sp, Nf, h->fac.flags, /*guard=*/false);
     sp_launch_band_axpy(s, Nf, sp.bsol, sp.brhs);
-    sp_launch_band_residual(s, sp, Nf);
+    sp_launch_band_residual(s, sp, Nf, h->fac.flags);
     HIPCHK(h, hipMemcpyAsync(h->h_bred, sp.bred, (size_t)2 * sp.nred * sizeof(double), hipMemcpyDeviceToHost, s));
     if (with_step) {
       unswap();
@@ -762,9 +779,6 @@ static int newton_core_async(pgf_handle h, bool *did_factor) {
       }
       sp_launch_bcr_solve(s, h->sp, Nf, h->fac.flags, h->refine_mode != 0);
       h->sp_guarded = h->refine_mode != 0;
-      if (h->sp_guarded)
-        (void)hipMemcpyAsync(h->h_bred, h->sp.bred, (size_t)2 * h->sp.nred * sizeof(double),
-                             hipMemcpyDeviceToHost, s);
       if (e0) {
         (void)hipEventRecord(e1, s);
         h->prof.update_spans.emplace_back(e0, e1);
@@ -772,8 +786,9 @@ static int newton_core_async(pgf_handle h, bool *did_factor) {
         // 4 x 512 B, rhs + solution 128 B) is written once and read about twice
         h->prof.update_flops.push_back(3.0 * (double)((Nf + 7) / 8) * (4 * 512 + 128));
       }
-      HIPCHK(h, hipMemcpyAsync(h->fac.h_flags, h->fac.flags, 4 * sizeof(int),
-                               hipMemcpyDeviceToHost, s));
+      if (!h->sp_guarded)
+        HIPCHK(h, hipMemcpyAsync(h->fac.h_flags, h->fac.flags, 4 * sizeof(int),
+                                 hipMemcpyDeviceToHost, s));
       *did_factor = true;  // flags need checking at the sync
     } else {
       h->sp_guarded = false;
@@ -785,6 +800,16 @@ static int newton_core_async(pgf_handle h, bool *did_factor) {
         sp_launch_fwdsolve(s, h->sp, Nf);
       }
       sp_launch_backsolve(s, h->sp, Nf);
+    }
+    if (h->sp_guarded) {
+      // ONE status block for the host: residual pairs, the step update's partial sums (summed
+      // on the host: no reduction kernel) and the pivot flags -- one copy instead of three
+      sp_launch_step_update(s, h->sp, h->n, h->m, h->fact, h->rho, h->x, h->y, h->lb, h->ub, h->F,
+                            h->dx, h->dy, h->xn, h->yn, h->sp.bred + 2 * h->sp.nred);
+      HIPCHK(h, hipMemcpyAsync(h->h_bred, h->sp.bred, ((size_t)3 * h->sp.nred + 4) * sizeof(double),
+                               hipMemcpyDeviceToHost, s));
+      h->sp_stat_pending = true;
+      return PGF_OK;
     }
     sp_launch_step_update(s, h->sp, h->n, h->m, h->fact, h->rho, h->x, h->y, h->lb, h->ub, h->F,
                           h->dx, h->dy, h->xn, h->yn, h->red);
@@ -829,7 +854,7 @@ int pgf_newton_solve(pgf_handle h, const double *x, const double *y, const doubl
   bool did_factor;
   for (int attempt = 0;; ++attempt) {
     if ((rc = newton_core_async(h, &did_factor))) return rc;
-    if ((rc = down(h, h->h_scal, h->scal, sizeof(double)))) return rc;
+    if (!h->sp_stat_pending && (rc = down(h, h->h_scal, h->scal, sizeof(double)))) return rc;
     if (did_factor) {
       rc = factor_finish(h);
       if (rc == PGF_RETRY_FACTOR) {  // once more, without the chain's helper workgroups
@@ -1056,8 +1081,8 @@ int pgf_sparse_set_pattern(pgf_handle h, int bw, const int *pos, int nnzH, const
     h->h_bred = nullptr;
   }
   sp.nred = (N + 255) / 256;
-  HIPCHK(h, dalloc(&sp.bred, (size_t)2 * sp.nred));
-  HIPCHK(h, hipHostMalloc((void **)&h->h_bred, (size_t)2 * (sp.nred ? sp.nred : 1) * sizeof(double)));
+  HIPCHK(h, dalloc(&sp.bred, (size_t)3 * sp.nred + 4));
+  HIPCHK(h, hipHostMalloc((void **)&h->h_bred, ((size_t)3 * sp.nred + 4) * sizeof(double)));
   HIPCHK(h, dalloc(&sp.Hb0, (size_t)n + 1));
   HIPCHK(h, dalloc(&sp.Jb0, (size_t)m + 1));
   {
@@ -1263,7 +1288,7 @@ int pgf_qp_step_async(pgf_handle h, unsigned policy, double tau) {
   std::swap(h->x, h->xn);
   std::swap(h->y, h->yn);
   h->eval_fresh = false;
-  if ((rc = down(h, h->h_scal, h->scal, sizeof(double)))) return rc;
+  if (!h->sp_stat_pending && (rc = down(h, h->h_scal, h->scal, sizeof(double)))) return rc;
   h->step_pending = true;
   return PGF_OK;
 }
@@ -1274,8 +1299,9 @@ int pgf_qp_sync(pgf_handle h, int *n_neg, double *diff) {
   h->step_pending = false;
   (void)hipSetDevice(h->device);
   hipError_t e;
-  int st = ldlt_finish(h->fac, &e);  // flags are only rewritten by a factor launch
   int rc;
+  if ((rc = sparse_status_sync(h))) return rc;
+  int st = ldlt_finish(h->fac, &e);  // flags are only rewritten by a factor launch
   if (st == 2) {
     // the chain's helper workgroups failed their checks (off now): the step is computed again
     // from the point it started at

@@ -18,8 +18,10 @@ struct SparseDev {
   // accuracy guard of the cyclic-reduction solves: the right-hand side as it was, the residual
   // of the solution, a saved solution (refinement), (max |r|, max |rhs|) per 256 rows
   double *brhs0 = nullptr, *bres = nullptr, *bsol = nullptr;
+  // bred: [0, 2 nred) the pairs, [2 nred, 3 nred) partial sums of the step update (guarded
+  // steps), [3 nred, 3 nred + 4) the solve's pivot flags
   double *bred = nullptr;
-  int nred = 0;  // pairs in bred
+  int nred = 0;
   double *Hb0 = nullptr, *Jb0 = nullptr;
   // block cyclic reduction work arrays: (N/8) blocks of 8 x 8 (D, L, U, inv D), rhs, solution
   double *bD = nullptr, *bL = nullptr, *bU = nullptr, *bDinv = nullptr, *bF = nullptr, *bX = nullptr;
@@ -46,7 +48,7 @@ void sp_launch_permute(hipStream_t s, const SparseDev &sp, int N, const double *
                        int gather);
 void sp_launch_factor(hipStream_t s, const SparseDev &sp, int N, int *flags);
 void sp_launch_bcr_solve(hipStream_t s, const SparseDev &sp, int N, int *flags, bool guard = true);
-void sp_launch_band_residual(hipStream_t s, const SparseDev &sp, int N);
+void sp_launch_band_residual(hipStream_t s, const SparseDev &sp, int N, const int *flags);
 void sp_launch_band_axpy(hipStream_t s, int N, const double *a, double *x);
 void sp_launch_fwdsolve(hipStream_t s, const SparseDev &sp, int N);
 void sp_launch_backsolve(hipStream_t s, const SparseDev &sp, int N);

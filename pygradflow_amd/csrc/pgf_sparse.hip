@@ -912,7 +912,11 @@ __global__ __launch_bounds__(256) void k_band_residual(const double *__restrict_
                                                        int N, const double *__restrict__ x,
                                                        const double *__restrict__ rhs0,
                                                        double *__restrict__ r,
-                                                       double *__restrict__ rsmax) {
+                                                       double *__restrict__ rsmax,
+                                                       const int *__restrict__ flags, int nred) {
+  // the pivot flags of the solve ride along behind the pairs and the step update's partial sums
+  // (one device-to-host copy for all three, pgf_api.hip)
+  if (blockIdx.x == 0 && threadIdx.x < 4) rsmax[3 * nred + threadIdx.x] = (double)flags[threadIdx.x];
   // rows [i0, i0 + 256 + bw) of the band (contiguous in memory: coalesced) and x[i0 - bw,
   // i0 + 256 + bw) staged in LDS: row i needs its own band row and, for the upper triangle, the
   // rows i + 1 .. i + bw of its neighbours (bw <= 10, ldb <= 12)
@@ -955,10 +959,10 @@ __global__ __launch_bounds__(256) void k_band_residual(const double *__restrict_
   }
 }
 
-void sp_launch_band_residual(hipStream_t s, const SparseDev &sp, int N) {
+void sp_launch_band_residual(hipStream_t s, const SparseDev &sp, int N, const int *flags) {
   if (N == 0) return;
   hipLaunchKernelGGL(k_band_residual, g1(N), dim3(256), 0, s, sp.band, sp.ldb, sp.bw, N, sp.brhs, sp.brhs0,
-                     sp.bres, sp.bred);
+                     sp.bres, sp.bred, flags, sp.nred);
 }
 
 // x = saved + correction (refinement step of the guard)
@@ -1049,5 +1053,5 @@ void sp_launch_bcr_solve(hipStream_t s, const SparseDev &sp, int N, int *flags, 
                          Fp(lev[q].set), sp.bX, nb, bs, bs, 2 * bs);
   }
   // (sp.bX IS sp.brhs: the back-substitution writes the solution where the caller reads it)
-  if (guard) sp_launch_band_residual(s, sp, N);
+  if (guard) sp_launch_band_residual(s, sp, N, flags);
 }
