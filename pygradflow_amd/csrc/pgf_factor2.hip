@@ -946,7 +946,11 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
         // tj in [sb, 3], of step sb - 2
         const int ndd = sb >= 1 ? (3 - sb) * (4 - sb) / 2 : 0;
         const int ndo = sb >= 2 ? ot * (4 - sb) : 0;
-        for (int e0 = wave - 4; e0 < ndd + ndo; e0 += NW - 4) {
+        // (wavefronts 4, 8, 12 share wavefront 0's SIMD: they stay out of its way)
+        const int w4 = wave - 4;
+        const int rk = (NW == 16) ? ((w4 & 3) ? w4 - (w4 >> 2) - 1 : -1) : w4;
+        const int nwk = (NW == 16) ? 9 : NW - 4;
+        for (int e0 = rk; rk >= 0 && e0 < ndd + ndo; e0 += nwk) {
           if (e0 < ndd) {
             int e = e0, tj = sb + 1;
             while (e >= 4 - tj) {
