@@ -48,8 +48,10 @@
 #define C_LD 66    // LDS row stride of 64-column tiles: conflict-free MFMA fragment reads
 #define C_WLD 18
 #define CH_ROWS 256
-// M[256][66] | Wt[2][64][18] | D[64] | 1/D[64] | flag | 1/D of the previous sub-panel [64]
-#define CH_SMEM (CH_ROWS * C_LD * 8 + 2 * 64 * C_WLD * 8 + 3 * 64 * 8 + 16)
+// M[256][66] | Wt[2][64][18] | D[64] | 1/D[64] | flag | 1/D of the previous sub-panel [64] |
+// Lt[2][16][16]: the factored 16 x 16 tile of a step, transposed (chain_b_own's multipliers)
+#define CH_LT_OFF (CH_ROWS * C_LD * 8 + 2 * 64 * C_WLD * 8 + 3 * 64 * 8 + 16)
+#define CH_SMEM (CH_LT_OFF + 2 * 16 * 16 * 8)
 
 // ------------------------------------------------------------------ TS x TS tile product
 // One 16 x 16 MFMA tile per wavefront of a (TS / 16)^2-wavefront workgroup:
@@ -339,7 +341,8 @@ __global__ __launch_bounds__(256) void kb_trsm_block(const BInst *__restrict__ t
 // and, in the same instruction stream, the tile rows below it; emits L into M, W = L D of the
 // rows below the 16 x 16 tile into Wt, D and 1/D.
 __device__ __forceinline__ void chain_a_plus(double (*M)[C_LD], double (*Wt)[C_WLD], double *dD,
-                                             double *dI, int &s_bad, int lane, int sb, int ncol) {
+                                             double *dI, int &s_bad, int lane, int sb, int ncol,
+                                             double (*Lt)[16]) {
   const int cb = sb * 16;
   double a[16], w[16];
 #pragma unroll
@@ -387,7 +390,10 @@ __device__ __forceinline__ void chain_a_plus(double (*M)[C_LD], double (*Wt)[C_W
     double d_mine = 1.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      if (k < tr) M[lane][cb + k] = a[k];
+      if (k < tr) {
+        M[lane][cb + k] = a[k];
+        Lt[k][tr] = a[k];  // transposed copy: row t = the multipliers of column t (chain_b_own)
+      }
       if (k == tr) d_mine = w[k];
     }
     const bool ok = !__builtin_amdgcn_class(d_mine, 0x1 | 0x2 | 0x4 | 0x20 | 0x40 | 0x200);
@@ -410,29 +416,67 @@ __device__ __forceinline__ void chain_a_plus(double (*M)[C_LD], double (*Wt)[C_W
 }
 
 // one lane per stack row below the diagonal tile: x L_bb^T = a_row for sub-block sbp; X (= L D)
-// replaces the row's entries in place.  L_bb: lane j & 15 loads ROW j of the factored tile once
-// and the multipliers are broadcast with v_readlane (scalar operands) -- reading the 120
-// entries as LDS broadcasts lets the scheduler hoist all of them into vector registers at once,
-// which does not fit the 128 registers a lane has in a 16-wavefront workgroup.
-__device__ __forceinline__ void chain_b_own(double (*M)[C_LD], int row, int sbp, int lane) {
+// replaces the row's entries in place.  The multipliers L_bb[j][t], j > t, come as 16-byte
+// broadcast reads from the TRANSPOSED copy of the factored tile that chain_a_plus leaves in LDS
+// (row t of Lt = column t of L_bb, contiguous in j): 64 reads + 120 FMAs.  With v_readlane
+// broadcasts out of a register copy of the tile (two per FMA, 360 instructions) this function,
+// not the pivot recurrence, bounded an elimination step: 2.05 us against 1.65 us for
+// chain_a_plus, each with a SIMD to itself (tools/chain_step_test.hip).
+// The reads are inline assembly with immediate offsets off ONE base register: as C++ loads the
+// compiler hoists the reads of all 15 columns to the top of the function and spills them -- a
+// lane has 128 registers in the 16-wavefront workgroup and the chain kernel uses 126 of them.
+template <int T, int P>
+__device__ __forceinline__ void chain_b_read(double2_t &m, unsigned base) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(m) : "v"(base), "n"((T * 16 + 2 * P) * 8));
+}
+template <int T>
+__device__ __forceinline__ void chain_b_col(double (&x)[16], unsigned base) {
+  // pairs (2 p, 2 p + 1) with an entry beyond column T: p >= (T + 1) / 2
+  constexpr int P0 = (T + 1) >> 1;
+  double2_t m[8];
+  if (0 >= P0) chain_b_read<T, 0>(m[0], base);
+  if (1 >= P0) chain_b_read<T, 1>(m[1], base);
+  if (2 >= P0) chain_b_read<T, 2>(m[2], base);
+  if (3 >= P0) chain_b_read<T, 3>(m[3], base);
+  if (4 >= P0) chain_b_read<T, 4>(m[4], base);
+  if (5 >= P0) chain_b_read<T, 5>(m[5], base);
+  if (6 >= P0) chain_b_read<T, 6>(m[6], base);
+  chain_b_read<T, 7>(m[7], base);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const double xt = x[T];
+#pragma unroll
+  for (int p = P0; p < 8; ++p) {
+    if (2 * p > T) x[2 * p] = fma(-xt, m[p].x, x[2 * p]);
+    x[2 * p + 1] = fma(-xt, m[p].y, x[2 * p + 1]);
+  }
+  __builtin_amdgcn_sched_barrier(0);  // eager (right-looking) order, see chain_a_plus
+}
+__device__ __forceinline__ void chain_b_own(double (*M)[C_LD], int row, int sbp, int lane,
+                                            const double (*Lt)[16]) {
   const int cb = sbp * 16;
-  double x[16], tl[16];
+  double x[16];
 #pragma unroll
   for (int k = 0; k < 16; k += 2) {
     const double2_t v = *reinterpret_cast<const double2_t *>(&M[row][cb + k]);
     x[k] = v.x;
     x[k + 1] = v.y;
-    const double2_t u = *reinterpret_cast<const double2_t *>(&M[cb + (lane & 15)][cb + k]);
-    tl[k] = u.x;
-    tl[k + 1] = u.y;
   }
-#pragma unroll
-  for (int t = 0; t < 15; ++t) {
-    const double xt = x[t];
-#pragma unroll
-    for (int j = t + 1; j < 16; ++j) x[j] = fma(-xt, lane_bcast(tl[t], j), x[j]);  // L_bb[j][t]
-    __builtin_amdgcn_sched_barrier(0);  // eager (right-looking) order, see chain_a_plus
-  }
+  const unsigned base = (unsigned)(uintptr_t)&Lt[0][0];  // LDS byte address
+  chain_b_col<0>(x, base);
+  chain_b_col<1>(x, base);
+  chain_b_col<2>(x, base);
+  chain_b_col<3>(x, base);
+  chain_b_col<4>(x, base);
+  chain_b_col<5>(x, base);
+  chain_b_col<6>(x, base);
+  chain_b_col<7>(x, base);
+  chain_b_col<8>(x, base);
+  chain_b_col<9>(x, base);
+  chain_b_col<10>(x, base);
+  chain_b_col<11>(x, base);
+  chain_b_col<12>(x, base);
+  chain_b_col<13>(x, base);
+  chain_b_col<14>(x, base);
 #pragma unroll
   for (int k = 0; k < 16; k += 2) {
     double2_t wv;
@@ -849,6 +893,7 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
   double *dD = reinterpret_cast<double *>(smem + CH_ROWS * C_LD * 8 + 2 * 64 * C_WLD * 8);
   double *dI = dD + 64;
   int &s_bad = *reinterpret_cast<int *>(dI + 64);
+  double(*Lt)[16][16] = reinterpret_cast<double(*)[16][16]>(smem + CH_LT_OFF);
   constexpr int NT = 64 * NW;  // NW = 16 or 8 wavefronts (8: 256 registers per lane)
   // wave: uniform per wavefront -> scalar register, role tests and tile numbers on the SALU
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -938,9 +983,9 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
       if (wave == 0) {
         // (step 0 of a stack built in place has been eliminated beside the tail of the
         // previous sub-panel's in-block update already)
-        if (!(early0 && sb == 0)) chain_a_plus(M, Wt + (sb & 1) * 64, dD, dI, s_bad, lane, sb, ncol);
+        if (!(early0 && sb == 0)) chain_a_plus(M, Wt + (sb & 1) * 64, dD, dI, s_bad, lane, sb, ncol, Lt[sb & 1]);
       } else if (wave <= 3) {
-        if (sb > 0 && 64 * (wave - 1) < own) chain_b_own(M, 64 * wave + lane, sb - 1, lane);
+        if (sb > 0 && 64 * (wave - 1) < own) chain_b_own(M, 64 * wave + lane, sb - 1, lane, Lt[(sb - 1) & 1]);
       } else {
         // deferred tiles: diagonal (ti, tj), tj in [sb + 1, 3], of step sb - 1; lower (ti, tj),
         // tj in [sb, 3], of step sb - 2
@@ -1041,7 +1086,7 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
         }
       }
       if (s == 0) CH_STAMP();  // C loads issued
-      if (wave >= 1 && wave <= 3 && 64 * (wave - 1) < own) chain_b_own(M, 64 * wave + lane, 3, lane);
+      if (wave >= 1 && wave <= 3 && 64 * (wave - 1) < own) chain_b_own(M, 64 * wave + lane, 3, lane, Lt[1]);
       for (int p = tid; p < 64 * 64; p += NT) {
         const int row = p >> 6, c = p & 63;
         if (c <= row) K[(int64_t)(cb + row) * ldk + cb + c] = M[row][c];
@@ -1120,7 +1165,7 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
       // no accumulator of the other path is live across the elimination, which has no
       // registers to spare)
       if (wave == 0) {
-        chain_a_plus(M, Wt, dD, dI, s_bad, lane, 0, 64);
+        chain_a_plus(M, Wt, dD, dI, s_bad, lane, 0, 64, Lt[0]);
         __syncthreads();  // C -> D
       } else {
 #pragma unroll
@@ -1133,7 +1178,7 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
       preloaded = true;
       early0 = true;
     } else {
-      if (wave >= 1 && wave <= 3 && 64 * (wave - 1) < own) chain_b_own(M, 64 * wave + lane, 3, lane);
+      if (wave >= 1 && wave <= 3 && 64 * (wave - 1) < own) chain_b_own(M, 64 * wave + lane, 3, lane, Lt[1]);
       __syncthreads();
       CH_STAMP();  // panel factored
 #pragma unroll
