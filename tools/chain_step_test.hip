@@ -1,6 +1,8 @@
-// chain_a_plus / chain_b_own of pgf_factor2.hip (copied by tools/make_chain_step_test.py) in
-// isolation: ONE wavefront eliminating a 16-column step of a 64 x 64 tile in LDS, and one
-// wavefront solving the rows below -- how long do they take with the CU to themselves?
+// chain_a_plus / chain_b_own of pgf_factor2.hip AS THEY WERE before chain_b_own took its
+// multipliers from LDS (a snapshot, copied in) in isolation: ONE wavefront eliminating a
+// 16-column step of a 64 x 64 tile in LDS, and one wavefront per 64 rows solving the rows below
+// -- how long do they take with the CU to themselves?  (MI355X: a+ 1.65 us per step, b 2.05 us:
+// the measurement that sent chain_b_own to LDS broadcast reads.)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef double double2_t __attribute__((ext_vector_type(2)));
