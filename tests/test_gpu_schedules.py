@@ -29,6 +29,7 @@ BATCH_VARIANTS = {
     "fused_lookahead": {},                          # default for small batches
     "chain_per_block": {"PGF_BATCH_FUSED_MAX": "0"},  # what larger batches run
     "split_panel_steps": {"PGF_BATCH_CHAIN": "0"},    # the round-1 schedule
+    "solves_per_super_block": {"PGF_TRSV_CHAIN": "0"},  # batched solves without the chained kernels
 }
 
 
