@@ -40,44 +40,40 @@
 #define C3_PLD 18  // row stride of the 16 x 16 LDS tiles: conflict-free ds_read_b128 of rows
 #define C3_LLD 66  // row stride of the 64 x 64 inverse workspace (= C_LD of pgf_factor2.hip)
 #define C3_PT_OFF 0                                  // next pivot tile, MFMA layout -> rows [16][18]
-#define C3_EI_OFF (C3_PT_OFF + 16 * C3_PLD * 8)      // inv(L_kk) of the last eight steps [8][16][18]
-#define C3_LK_OFF (C3_EI_OFF + 8 * 16 * C3_PLD * 8)  // factored pivot tile [4][16][18]
+#define C3_NEI 6                                     // inv(L_kk) of the last six steps
+#define C3_EI_OFF (C3_PT_OFF + 16 * C3_PLD * 8)      // [C3_NEI][16][18]
+#define C3_LK_OFF (C3_EI_OFF + C3_NEI * 16 * C3_PLD * 8)  // factored pivot tile [4][16][18]
 #define C3_D_OFF (C3_LK_OFF + 4 * 16 * C3_PLD * 8)   // D[4][16] | 1/D[4][16] | counters
 #define C3_ST_OFF (C3_D_OFF + 8 * 16 * 8 + 16)       // parked tiles: B operand [4][64] | C [4][64]
-#define C3_XW_OFF (C3_ST_OFF + 2 * 256 * 8)          // wavefront 0's panel tile [2][4][64]
-#define C3_XP_OFF (C3_XW_OFF + 2 * 256 * 8)          // X panel [16 tiles][4][64]
-#define C3_LG_OFF (C3_XP_OFF + 16 * 256 * 8)         // [2][64][66]: L of a 64-group below, inv^T above
-#define C3_DU_OFF (C3_LG_OFF + 2 * 64 * C3_LLD * 8)  // where the copies' rows of the factored tile go [64][18]
-#define C3_SMEM (C3_DU_OFF + 64 * C3_PLD * 8)
+#define C3_XW_OFF (C3_ST_OFF + 2 * 256 * 8)          // wavefront 0's panel tile, as -L [3][4][64]
+#define C3_XP_OFF (C3_XW_OFF + 3 * 256 * 8)          // X panels of two steps [2][16 tiles][4][64]
+#define C3_LG_OFF (C3_XP_OFF + 2 * 16 * 256 * 8)     // inverse workspace [2 groups][12 blocks][16][18]
+#define C3_SMEM (C3_LG_OFF + 2 * 12 * 16 * C3_PLD * 8)
 
-// Tile (i, l) of wavefront w - 1, slot q: i | l << 4; nine tiles each (tile (0, 0), the first pivot
-// tile, goes from global memory to the elimination and has no owner).
+// Tile (i, l) of owner o, slot q: i | l << 4 (0xf0: none); the owners are the wavefronts of SIMDs
+// 1..3 (1, 2, 3, 5, 6, 7, 9, ...): wavefronts 4, 8, 12 share SIMD 0 with wavefront 0, whose
+// elimination ANY FP64 MFMA on that SIMD stalls for up to 64 cycles per instruction (measured:
+// 2-5 x slower) -- they do the write-backs instead.  Tile (0, 0), the first pivot tile, goes from
+// global memory to the elimination and has no owner.
 //   * The band (j, j - 2), (j, j - 1), (j, j) of tile row j has ONE owner: in step j - 1 it finishes
 //     panel tile (j, j - 2), updates (j, j - 1) and (j, j) from its own registers and parks them
 //     for wavefront 0 -- without waiting for any other wavefront.
-//   * Wavefronts 4, 8, 12 share SIMD 0 with wavefront 0, whose elimination their MFMAs slow down
-//     2-4 x: they own tiles of the columns 0..6 only, far from the diagonal and spread over the
-//     columns, and are done after step 6 -- while the owners' matrix work, not the elimination,
-//     bounds a step.
-//   * The rest is dealt for an even number of live tiles per wavefront throughout and few tiles
-//     of one column on one wavefront.
-#define C3_NS 9
-__device__ static const unsigned char c3_tab[15][C3_NS] = {
-    {0x01, 0x11, 0xbd, 0xcd, 0xdd, 0x7b, 0x6c, 0x2a, 0x09},
-    {0x02, 0x12, 0x22, 0xce, 0xde, 0xee, 0x6b, 0x39, 0x08},
-    {0x13, 0x23, 0x33, 0xdf, 0xef, 0xff, 0x04, 0x07, 0x0b},
-    {0x0f, 0x0c, 0x1d, 0x2e, 0x3f, 0x3c, 0x4d, 0x5e, 0x6f},
-    {0x24, 0x34, 0x44, 0xcf, 0xaf, 0x8c, 0x7d, 0x15, 0x03},
-    {0x35, 0x45, 0x55, 0xbe, 0x9c, 0x8d, 0x7e, 0x28, 0x18},
-    {0x46, 0x56, 0x66, 0xbf, 0x9d, 0x8f, 0x38, 0x27, 0x17},
-    {0x0e, 0x1f, 0x1c, 0x2d, 0x3e, 0x4f, 0x4c, 0x5d, 0x6e},
-    {0x57, 0x67, 0x77, 0xad, 0x9e, 0x48, 0x37, 0x26, 0x16},
-    {0x68, 0x78, 0x88, 0xae, 0x9f, 0x59, 0x49, 0x3a, 0x1a},
-    {0x79, 0x89, 0x99, 0x69, 0x58, 0x47, 0x36, 0x25, 0x14},
-    {0x0d, 0x1e, 0x2f, 0x2c, 0x3d, 0x4e, 0x5f, 0x5c, 0x6d},
-    {0x8a, 0x9a, 0xaa, 0x7a, 0x6a, 0x5a, 0x4a, 0x3b, 0x1b},
-    {0x9b, 0xab, 0xbb, 0x8b, 0x7c, 0x5b, 0x29, 0x19, 0x05},
-    {0xac, 0xbc, 0xcc, 0x8e, 0x7f, 0x4b, 0x2b, 0x06, 0x0a}};
+//   * The rest is dealt for an even number of live tiles per owner throughout and few tiles of
+//     one column on one owner.
+#define C3_NS 12
+__device__ static const unsigned char c3_tab[12][C3_NS] = {
+    {0x01, 0x11, 0xbd, 0xcd, 0xdd, 0x7b, 0x6c, 0x5e, 0x4e, 0x3d, 0x2c, 0xf0},
+    {0x02, 0x12, 0x22, 0xce, 0xde, 0xee, 0x6b, 0x5d, 0x4d, 0x3c, 0xf0, 0xf0},
+    {0x13, 0x23, 0x33, 0xdf, 0xef, 0xff, 0x5c, 0x4c, 0x09, 0xf0, 0xf0, 0xf0},
+    {0x24, 0x34, 0x44, 0xcf, 0xaf, 0x8c, 0x7d, 0x6e, 0x17, 0x05, 0x0d, 0xf0},
+    {0x35, 0x45, 0x55, 0xbe, 0x9c, 0x8d, 0x7e, 0x6f, 0x2a, 0x1a, 0x08, 0xf0},
+    {0x46, 0x56, 0x66, 0xbf, 0x9d, 0x8f, 0x38, 0x27, 0x14, 0x1d, 0x03, 0x0c},
+    {0x57, 0x67, 0x77, 0xad, 0x9e, 0x48, 0x37, 0x25, 0x2e, 0x15, 0x1e, 0x04},
+    {0x68, 0x78, 0x88, 0xae, 0x9f, 0x59, 0x49, 0x39, 0x28, 0x18, 0x06, 0x0e},
+    {0x79, 0x89, 0x99, 0x69, 0x58, 0x47, 0x36, 0x3f, 0x26, 0x2f, 0x16, 0x1f},
+    {0x8a, 0x9a, 0xaa, 0x7a, 0x6a, 0x5a, 0x4a, 0x3a, 0x29, 0x19, 0x07, 0x0f},
+    {0x9b, 0xab, 0xbb, 0x8b, 0x7c, 0x6d, 0x5f, 0x4f, 0x3e, 0x2d, 0x1c, 0x0b},
+    {0xac, 0xbc, 0xcc, 0x8e, 0x7f, 0x5b, 0x4b, 0x3b, 0x2b, 0x1b, 0x0a, 0xf0}};
 
 // lane L of the own row of 16 lanes -> every lane of the row
 template <int L>
@@ -113,12 +109,12 @@ __device__ __forceinline__ int c3_ld(const int *p) {
 
 // Column C of the elimination.  a[]: the lane's row of the tile (entries j <= row valid; what
 // sits above the diagonal never reaches a valid result), e[]: its row of inv(L) in the making,
-// lkrow[C] <- -L[row][C] (0 on and above the diagonal; LDS: the row of the factored tile, or a
-// dump for the lanes that hold copies), r: 1 / a[C] of the own lane (meaningful in lane C),
+// -L[row][C] (0 on and above the diagonal) goes to LDS at byte address lkrow + 8 C from lanes
+// 0..15 (the other lanes hold copies), r: 1 / a[C] of the own lane (meaningful in lane C),
 // npc: -a[C] * a[C + 1][C]; dmine <- the pivot of the own row, dsel[s] <- 1 / D[4 s + q] (q = the
 // lane's row of 16 lanes: the D^-1 entries its MFMA operands need).
 template <int C>
-__device__ __forceinline__ void c3_col(double (&a)[16], double (&e)[16], double *lkrow, double &r,
+__device__ __forceinline__ void c3_col(double (&a)[16], double (&e)[16], unsigned lkrow, double &r,
                                        double &npc, double &dmine, double (&dsel)[4], int row, int q) {
   constexpr int C1 = (C + 1) & 15, C2 = (C + 2) & 15;
   double rn = 0.0, npn = 0.0;
@@ -129,7 +125,10 @@ __device__ __forceinline__ void c3_col(double (&a)[16], double (&e)[16], double 
   }
   const double rb = c3_bcast<C>(r);
   const double l = (row > C) ? -a[C] * rb : 0.0;
-  lkrow[C] = l;
+  asm volatile("s_mov_b64 exec, 0xffff\n\tds_write_b64 %0, %1 offset:%2\n\ts_mov_b64 exec, -1"
+               :
+               : "v"(lkrow), "v"(l), "n"(C * 8)
+               : "memory");
   if (C + 2 < 16) npn = -a[C1] * c3_bcast<C2>(a[C1]);
 #define C3_UA(K) \
   if (K > C + 1) c3_fmac<K>(a[K], a[C], l);
@@ -156,7 +155,7 @@ __device__ __forceinline__ void c3_col(double (&a)[16], double (&e)[16], double 
 // wavefront 0: LDL^T of the tile in a[] (lane <-> row in each row of 16 lanes).  Leaves -L in
 // lkrow[] (LDS), inv(L) in e[], the own row's pivot in dmine and 1 / D[4 s + q] in dsel[s] (one
 // Newton step).
-__device__ __forceinline__ void c3_eliminate(double (&a)[16], double *lkrow, double (&e)[16],
+__device__ __forceinline__ void c3_eliminate(double (&a)[16], unsigned lkrow, double (&e)[16],
                                              double &dmine, double (&dsel)[4], int row, int q) {
   double r = __builtin_amdgcn_rcp(a[0]);
   r = fma(r, fma(-a[0], r, 1.0), r);
@@ -180,32 +179,34 @@ __device__ __forceinline__ void c3_eliminate(double (&a)[16], double *lkrow, dou
   c3_col<15>(a, e, lkrow, r, npc, dmine, dsel, row, q);
 }
 
-// One block of the inverse of the unit-lower 64 x 64 tile of a 64-group.  Lg holds the group's
-// L blocks below the diagonal (block (p, r) at rows 16 p, columns 16 r) and, transposed, the
-// finished inverse blocks ABOVE it (X_rq^T at rows 16 q, columns 16 r); Ep = inv(L_pp) and
-// Eq = inv(L_qq), row-major with stride C3_PLD (the ring of the last eight steps' inverses).
+// One block of the inverse of the unit-lower 64 x 64 tile of a 64-group.  The group's workspace
+// holds twelve 16 x 18 blocks: L block (p, r), r < p, at index p (p - 1) / 2 + r, and the finished
+// inverse block X_pq, transposed, at 6 + p (p - 1) / 2 + q; Ep = inv(L_pp) and Eq = inv(L_qq) come
+// from the ring of the last steps' inverses (row-major, stride C3_PLD).
 //   X_pq = -inv(L_pp) (L_pq inv(L_qq) + sum_{q < r < p} L_pr X_rq),   q < p,
 // with MFMA: a 16 x 16 accumulator IS the B operand of the next four k-steps.
-// Writes X_pq into Lg (above the diagonal) and into inv / inv^T ([row][64] each).
-__device__ __forceinline__ void c3_inverse_block(double (*Lg)[C3_LLD], const double *Ep, const double *Eq,
-                                                 int p, int q, int l15, int l4, double *__restrict__ o,
+// Writes X_pq^T into the workspace and X_pq into inv / inv^T ([row][64] each).
+__device__ __forceinline__ double *c3_lblock(double *Lg, int p, int r) { return Lg + (p * (p - 1) / 2 + r) * 16 * C3_PLD; }
+__device__ __forceinline__ void c3_inverse_block(double *Lg, const double *Ep, const double *Eq, int p, int q,
+                                                 int l15, int l4, double *__restrict__ o,
                                                  double *__restrict__ ot) {
   double4_t S = (double4_t){0.0, 0.0, 0.0, 0.0};
   for (int r = q; r < p; ++r) {
+    const double *Lpr = c3_lblock(Lg, p, r) + l15 * C3_PLD + l4;
+    const double *Xrq = (r == q) ? Eq + l4 * C3_PLD + l15 : c3_lblock(Lg, r, q) + 6 * 16 * C3_PLD + l15 * C3_PLD + l4;
+    const int xs = (r == q) ? 4 * C3_PLD : 4;  // k-step stride: rows of E_q, columns of X_rq^T
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const double b = (r == q) ? Eq[(4 * rr + l4) * C3_PLD + l15] : Lg[16 * q + l15][16 * r + 4 * rr + l4];
-      S = __builtin_amdgcn_mfma_f64_16x16x4f64(Lg[16 * p + l15][16 * r + 4 * rr + l4], b, S, 0, 0, 0);
-    }
+    for (int rr = 0; rr < 4; ++rr) S = __builtin_amdgcn_mfma_f64_16x16x4f64(Lpr[4 * rr], Xrq[xs * rr], S, 0, 0, 0);
   }
   double4_t X = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr)
     X = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ep[l15 * C3_PLD + 4 * rr + l4], S[rr], X, 0, 0, 0);
+  double *Xt = c3_lblock(Lg, p, q) + 6 * 16 * C3_PLD;
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     const int a = l4 + 4 * rr;  // row inside block (p, q), column l15
-    Lg[16 * q + l15][16 * p + a] = X[rr];
+    Xt[l15 * C3_PLD + a] = X[rr];
     o[(16 * p + a) * 64 + 16 * q + l15] = X[rr];
     ot[(16 * q + l15) * 64 + 16 * p + a] = X[rr];
   }
@@ -218,424 +219,3 @@ __device__ __forceinline__ void c3_inverse_block(double (*Lg)[C3_LLD], const dou
 //   Linv / LinvT  inverses of the unit-lower 64 x 64 diagonal tiles and their transposes
 //   dbg    optional phase stamps (wall clock; shader cycles 64 entries further): [0, 32)
 //          wavefront 0, [32, 64) wavefront 5
-__device__ __forceinline__ void chain3_body(unsigned char *smem, double *K, int64_t ldk, int c0, int nb,
-                                            double *__restrict__ dvec, double *__restrict__ dinv,
-                                            int *__restrict__ flags, double *__restrict__ Linv,
-                                            double *__restrict__ LinvT, long long *__restrict__ dbg) {
-  double *PT = reinterpret_cast<double *>(smem + C3_PT_OFF);
-  double *EI = reinterpret_cast<double *>(smem + C3_EI_OFF);  // [8][16][18]
-  double *LK = reinterpret_cast<double *>(smem + C3_LK_OFF);  // [4][16][18]: L_kk, D on the diagonal
-  double *Dl = reinterpret_cast<double *>(smem + C3_D_OFF);    // D [4][16], then 1/D [4][16]
-  int *cnt = reinterpret_cast<int *>(smem + C3_D_OFF + 8 * 16 * 8);  // panel tiles in LDS (running sum)
-  int *stg = cnt + 1;                                                // steps whose two tiles are parked
-  double *STB = reinterpret_cast<double *>(smem + C3_ST_OFF), *STC = STB + 256;
-  double *XW = reinterpret_cast<double *>(smem + C3_XW_OFF);  // [2][4][64]
-  double *XP = reinterpret_cast<double *>(smem + C3_XP_OFF);
-  double(*Lg)[C3_LLD] = reinterpret_cast<double(*)[C3_LLD]>(smem + C3_LG_OFF);  // two groups of 64 rows
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l15 = lane & 15, l4 = lane >> 4;
-  const int bend = c0 + nb;
-  const int nst = (nb + 15) >> 4;  // 16-column steps
-  int dbi = 0;
-  (void)dbi;
-#ifdef C3_TIMING
-#define C3_STAMP()                     \
-  do {                                 \
-    if (dbg && tid == 0 && dbi < 32) { \
-      dbg[64 + dbi] = clock64();       \
-      dbg[dbi++] = wall_clock64();     \
-    }                                  \
-  } while (0)
-#else
-#define C3_STAMP() \
-  do {             \
-  } while (0)
-#endif
-  C3_STAMP();
-  int dbo = 32;
-  (void)dbo;
-#ifdef C3_TIMING
-#define C3_OSTAMP(cond)                                                       \
-  do {                                                                        \
-    if (dbg && tid == 320 && (cond) && dbo < 64) dbg[dbo++] = wall_clock64(); \
-  } while (0)
-#else
-#define C3_OSTAMP(cond) \
-  do {                  \
-  } while (0)
-#endif
-
-  // the inverse workspace starts as identity
-  for (int p = tid; p < 2 * 64 * C3_LLD; p += 1024) {
-    const int rr = (p / C3_LLD) & 63, cc = p % C3_LLD;
-    (&Lg[0][0])[p] = (rr == cc) ? 1.0 : 0.0;
-  }
-  // inv / inv^T of the block's 64 x 64 tiles: zeros above the diagonal, identity where a ragged
-  // last tile has no rows (everything else is written block by block as the chain advances)
-  for (int g = 0; g < (nb + 63) >> 6; ++g) {
-    double *o = Linv + (size_t)((c0 >> 6) + g) * 4096, *ot = LinvT + (size_t)((c0 >> 6) + g) * 4096;
-    for (int p = tid; p < 4096; p += 1024) {
-      const int rr = p >> 6, cc = p & 63;
-      const bool above = (cc >> 4) > (rr >> 4);
-      const bool norow = 64 * g + (rr & ~15) >= 16 * nst, nocol = 64 * g + (cc & ~15) >= 16 * nst;
-      if (above || norow) o[p] = (rr == cc) ? 1.0 : 0.0;
-      if ((rr >> 4) > (cc >> 4) || nocol) ot[p] = (rr == cc) ? 1.0 : 0.0;
-    }
-  }
-  if (tid == 0) {
-    *cnt = 0;
-    *stg = 0;
-  }
-
-  // Two role loops with the same barrier sequence (one, then one per step): the roles' register
-  // needs differ (elimination: three 16-entry rows; tile owners: nine accumulators), and in one
-  // loop the compiler keeps both sets alive across each other's code and spills.
-  if (wave == 0) {
-    {
-      // pivot tile of step 0: from global memory (identity beyond the block's end) to where every
-      // step finds its tile
-      const int row = c0 + l15;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int col = c0 + l4 + 4 * r;
-        double v = (row == col) ? 1.0 : 0.0;
-        if (row < bend) v = (col <= row) ? K[(int64_t)row * ldk + col] : 0.0;
-        PT[l15 * C3_PLD + l4 + 4 * r] = v;
-      }
-    }
-    bool bad = false;
-    int neg = 0;
-    c3_barrier();
-    C3_STAMP();
-    for (int k = 0; k < nst; ++k) {
-      const int ncol = min(16, bend - (c0 + 16 * k));
-      double e[16], dsel[4] = {0.0, 0.0, 0.0, 0.0}, dmine;
-      {
-        // (lane indices laundered around the elimination: otherwise every LDS address of the
-        // step is computed up front and kept alive across it, where a lane has no register to
-        // spare, and spilled)
-        int ln = threadIdx.x;
-        asm volatile("" : "+v"(ln));
-        // the pivot tile, lane <-> row (from the MFMA layout through LDS; not carried in
-        // registers from the end of the previous step: the compiler then keeps two copies)
-        double a[16];
-#pragma unroll
-        for (int j = 0; j < 16; j += 2) {
-          const double2_t v = *reinterpret_cast<const double2_t *>(PT + (ln & 15) * C3_PLD + j);
-          a[j] = v.x;
-          a[j + 1] = v.y;
-        }
-        // (-L_kk goes to LDS column by column: a tile owner takes it to global memory two steps on)
-        double *lkrow = (ln < 16) ? LK + ((k & 3) * 16 + ln) * C3_PLD
-                                  : reinterpret_cast<double *>(smem + C3_DU_OFF) + ln * C3_PLD;
-        c3_eliminate(a, lkrow, e, dmine, dsel, ln & 15, ln >> 4);
-        if (ln < 16) lkrow[ln] = dmine;
-      }
-      if (k == 1 || k == 14) C3_STAMP();  // elimination
-      int ln = threadIdx.x;
-      asm volatile("" : "+v"(ln));
-      const int r15 = ln & 15, r4 = ln >> 4;
-      const double imine = fast_recip(dmine);
-      {
-        const bool mine = ln < 16 && r15 < ncol;
-        bad |= __ballot(mine && __builtin_amdgcn_class(dmine, C3_BAD_CLASS)) != 0ull;
-        neg += __popcll(__ballot(mine && dmine < 0.0));
-      }
-      // inv(L_kk) leaves the registers as the MFMA operand each lane needs of it -- entries
-      // (row, 4 s + its row of 16 lanes) -- and goes to LDS from all 64 lanes in that shape: four
-      // 8-byte stores instead of eight 16-byte stores of 16 lanes (an LDS store costs ~20 cycles
-      // per 8 bytes of a lane)
-      double as[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        as[s] = (r4 == 0) ? e[4 * s] : (r4 == 1) ? e[4 * s + 1] : (r4 == 2) ? e[4 * s + 2] : e[4 * s + 3];
-      double *ei = EI + ((k & 7) * 16 + r15) * C3_PLD + r4;
-      if (k + 1 < nst) {
-        // ---- panel tile (k + 1, k) and the next pivot tile (k + 1, k + 1), parked by their owner
-        for (int it = 0; it < (1 << 22) && c3_ld(stg) < k + 1; ++it) __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
-        double bt[4];
-        double4_t x = (double4_t){0.0, 0.0, 0.0, 0.0}, t;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) bt[s] = STB[64 * s + ln];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) t[r] = STC[64 * r + ln];
-        // (what the owners wait for goes out while the matrix pipe works)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) ei[4 * s] = as[s];
-        if (ln < 16) {
-          Dl[16 * (k & 3) + r15] = dmine;
-          Dl[64 + 16 * (k & 3) + r15] = imine;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) x = __builtin_amdgcn_mfma_f64_16x16x4f64(as[s], bt[s], x, 0, 0, 0);
-        // the panel tile is published as -L = -X D^-1: every live tile it meets lies below its
-        // tile row, where it is the scaled operand (and the write-back wants L)
-        double *xo = XW + (k & 1) * 256 + ln;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const double nls = -x[s] * dsel[s];
-          xo[64 * s] = nls;
-          t = __builtin_amdgcn_mfma_f64_16x16x4f64(nls, x[s], t, 0, 0, 0);
-        }
-        // next pivot tile: MFMA layout -> (next step) lane <-> row through LDS
-#pragma unroll
-        for (int r = 0; r < 4; ++r) PT[r15 * C3_PLD + r4 + 4 * r] = t[r];
-      } else {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) ei[4 * s] = as[s];
-        if (ln < 16) {
-          Dl[16 * (k & 3) + r15] = dmine;
-          Dl[64 + 16 * (k & 3) + r15] = imine;
-        }
-      }
-      if (k == 1 || k == 14) C3_STAMP();  // panel tile, next pivot tile
-      c3_barrier();  // step k is published: inv(L_kk), D, panel tile (k + 1, k), the factored tile
-      C3_STAMP();
-    }
-    c3_barrier();  // (the owners' last write-back reads the last factored tile)
-    if (lane == 0) {
-      if (bad) atomicOr(&flags[0], 1);
-      if (neg) atomicAdd(&flags[1], neg);
-    }
-  } else {
-    // ---- this wavefront's tiles
-    int ti[C3_NS], tl[C3_NS];
-    double4_t acc[C3_NS];
-#pragma unroll
-    for (int q = 0; q < C3_NS; ++q) {
-      const int v = c3_tab[wave - 1][q];
-      ti[q] = ((v & 15) >= nst) ? -1 : (v & 15);
-      tl[q] = v >> 4;
-    }
-#pragma unroll
-    for (int q = 0; q < C3_NS; ++q) {
-      acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
-      if (ti[q] >= 0) {
-        const int row = c0 + 16 * ti[q] + l15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int col = c0 + 16 * tl[q] + l4 + 4 * r;
-          double v = (row == col) ? 1.0 : 0.0;  // identity beyond the block's end
-          if (row < bend) v = (col <= row) ? K[(int64_t)row * ldk + col] : 0.0;
-          acc[q][r] = v;
-        }
-      }
-    }
-    unsigned pend = 0;  // bit i: panel tile (i, kk) of this wavefront waits for its write-back
-    int parked = -1;    // panel tile (parked, k): wavefront 0 computes it from this wavefront's tile
-    int tgt = 0;        // panel tiles counted in by the end of the current step
-    const int wr = lane >> 2, wc4 = lane & 3;
-    // panel tile `it` of step kk (in the panel buffer, or wavefront 0's own buffer for the tile
-    // right below the pivot tile) -> L = X D^-1 in global memory, four lanes per row
-    auto write_panel_tile = [&](int it, int kk) {
-      const double *Dip = Dl + 64 + 16 * (kk & 3);
-      const int row = c0 + 16 * it + wr;
-      const bool w0 = it == kk + 1;  // wavefront 0's tile: -L already
-      const double *xs = (w0 ? XW + (kk & 1) * 256 : XP + (size_t)(it * 256)) + wc4 * 64 + wr;
-      double2_t lo, hi;
-      lo.x = w0 ? -xs[0] : xs[0] * Dip[4 * wc4];
-      lo.y = w0 ? -xs[16] : xs[16] * Dip[4 * wc4 + 1];
-      hi.x = w0 ? -xs[32] : xs[32] * Dip[4 * wc4 + 2];
-      hi.y = w0 ? -xs[48] : xs[48] * Dip[4 * wc4 + 3];
-      if (row < bend) {
-        double *dst = K + (int64_t)row * ldk + c0 + 16 * kk + 4 * wc4;
-        *reinterpret_cast<double2_t *>(dst) = lo;
-        *reinterpret_cast<double2_t *>(dst + 2) = hi;
-      }
-    };
-    // the factored pivot tile of step kk with D and 1 / D (one wavefront in turn)
-    auto write_pivot_tile = [&](int kk) {
-      if (kk < 0 || wave != 1 + kk % 15) return;
-      const int row = c0 + 16 * kk + wr;
-      const double *lk = LK + ((kk & 3) * 16 + wr) * C3_PLD + 4 * wc4;
-      if (row < bend) {
-        double *dst = K + (int64_t)row * ldk + c0 + 16 * kk + 4 * wc4;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          if (4 * wc4 + t <= wr) dst[t] = (4 * wc4 + t == wr) ? lk[t] : -lk[t];
-        if (wc4 == 0) {
-          dvec[row] = Dl[16 * (kk & 3) + wr];
-          dinv[row] = Dl[64 + 16 * (kk & 3) + wr];
-        }
-      }
-    };
-    // the two tiles wavefront 0 needs in step k -- T(k + 1, k) as the B operand of its panel
-    // product, pivot tile (k + 1, k + 1) as the accumulator of its update -- go to LDS
-    auto park = [&](int k) {
-      if (k + 1 >= nst) return;
-      bool mine = false;
-#pragma unroll
-      for (int q = 0; q < C3_NS; ++q) {
-        if (ti[q] == k + 1 && tl[q] == k) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s) STB[64 * s + lane] = acc[q][s];
-          ti[q] = -1;
-          parked = k + 1;
-          mine = true;
-        }
-        if (ti[q] == k + 1 && tl[q] == k + 1) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) STC[64 * r + lane] = acc[q][r];
-          ti[q] = -1;
-        }
-      }
-      if (mine) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(stg, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-    };
-    park(0);
-    c3_barrier();
-    for (int k = 1; k <= nst; ++k) {
-      // ---- the owners' share of step kk = k - 1, beside wavefront 0's step k
-      c3_barrier();  // wavefront 0 has published step kk: inv(L_kk), D, panel tile (k, kk)
-      // (tile indices laundered per step: otherwise every LDS address of every slot is hoisted
-      // out of the loop and kept alive beside the accumulators)
-#pragma unroll
-      for (int q = 0; q < C3_NS; ++q) asm volatile("" : "+s"(ti[q]), "+s"(tl[q]));
-      const int kk = k - 1;
-      const double *Dip = Dl + 64 + 16 * (kk & 3);
-      const double *xw = XW + (kk & 1) * 256 + lane;  // panel tile (k, kk)
-      const double *ei = EI + ((kk & 7) * 16 + l15) * C3_PLD + l4;
-      double(*Lgk)[C3_LLD] = Lg + 64 * ((kk >> 2) & 1);
-      const int wb_parked = parked;  // == k: that tile is in wavefront 0's buffer now
-      parked = -1;
-      C3_OSTAMP(k == 2 || k == 13);
-      double dq[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) dq[s] = Dip[4 * s + l4];
-      // panel tile of slot q: X^T = inv(L_kk) T^T -> x (MFMA C layout = operand layout of the
-      // updates), panel buffer, inverse workspace
-      auto panel_tile = [&](int q, double4_t &x) {
-        x = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) x = __builtin_amdgcn_mfma_f64_16x16x4f64(ei[4 * s], acc[q][s], x, 0, 0, 0);
-        double *xo = XP + (size_t)(ti[q] * 256) + lane;
-        const bool ingroup = (ti[q] >> 2) == (kk >> 2);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          xo[64 * s] = x[s];
-          if (ingroup) Lgk[16 * (ti[q] & 3) + l15][16 * (kk & 3) + 4 * s + l4] = x[s] * dq[s];
-        }
-        pend |= 1u << ti[q];
-        ti[q] = -1;  // final
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      };
-      // ---- the band of tile row k + 1, if it is this wavefront's: panel tile (k + 1, kk), then
-      // from registers the two tiles wavefront 0 takes over in step k
-      if (k + 1 < nst) {
-        double4_t xb;
-        bool band = false;
-#pragma unroll
-        for (int q = 0; q < C3_NS; ++q) {
-          if (ti[q] == k + 1 && tl[q] == kk) {
-            panel_tile(q, xb);
-            band = true;
-          }
-        }
-        if (band) {
-#pragma unroll
-          for (int q = 0; q < C3_NS; ++q) {
-            if (ti[q] == k + 1 && tl[q] == k) {
-#pragma unroll
-              for (int s = 0; s < 4; ++s)
-                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xw[64 * s], xb[s], acc[q], 0, 0, 0);
-            }
-            if (ti[q] == k + 1 && tl[q] == k + 1) {
-#pragma unroll
-              for (int s = 0; s < 4; ++s)
-                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xb[s] * dq[s], xb[s], acc[q], 0, 0, 0);
-            }
-          }
-        }
-        park(k);
-      }
-      // ---- the rest of panel kk
-#pragma unroll
-      for (int q = 0; q < C3_NS; ++q) {
-        if (ti[q] > k && tl[q] == kk) {
-          double4_t x;
-          panel_tile(q, x);
-        }
-      }
-      tgt += max(0, nst - k - 1);
-      C3_OSTAMP(k == 2 || k == 13);
-      for (int it = 0; it < (1 << 22) && c3_ld(cnt) < tgt; ++it) __builtin_amdgcn_s_sleep(1);
-      asm volatile("" ::: "memory");
-      C3_OSTAMP(k == 2 || k == 13);
-      // ---- step kk's update of every live tile.  Panel tile (k, kk) is wavefront 0's and comes as
-      // -L: every live tile it meets has it on the column side, where the operand is scaled.
-#pragma unroll
-      for (int q = 0; q < C3_NS; ++q) {
-        if (ti[q] >= 0 && tl[q] >= k) {
-          const double *xi = XP + (size_t)(ti[q] * 256) + lane;
-          // (two k-steps at a time: with all eight operands of a tile in flight at once the
-          // nine accumulators do not fit the 128 registers of a lane)
-          if (tl[q] == k) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-              acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xw[64 * s], xi[64 * s], acc[q], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 2; s < 4; ++s)
-              acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xw[64 * s], xi[64 * s], acc[q], 0, 0, 0);
-          } else {
-            const double *xl = XP + (size_t)(tl[q] * 256) + lane;
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-              acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xl[64 * s] * dq[s], xi[64 * s], acc[q], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 2; s < 4; ++s)
-              acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xl[64 * s] * dq[s], xi[64 * s], acc[q], 0, 0, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      C3_OSTAMP(k == 2 || k == 13);
-      // ---- write-back: this wavefront's panel tiles of step kk; the panel tile wavefront 0
-      // computed from this wavefront's parked tile (and its copy in the inverse workspace); the
-      // factored pivot tile of the step before
-      while (pend) {
-        const int it = __builtin_ctz(pend);
-        pend &= pend - 1;
-        write_panel_tile(it, kk);
-      }
-      if (wb_parked >= 0) {
-        write_panel_tile(wb_parked, kk);
-        if ((wb_parked >> 2) == (kk >> 2)) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s) Lgk[16 * (wb_parked & 3) + l15][16 * (kk & 3) + 4 * s + l4] = -xw[64 * s];
-        }
-      }
-      write_pivot_tile(kk - 1);
-      // ---- block row kk & 3 of the group's 64 x 64 inverse: one wavefront per block
-      {
-        const int p = kk & 3, g = kk >> 2;
-        double *o = Linv + (size_t)((c0 >> 6) + g) * 4096, *ot = LinvT + (size_t)((c0 >> 6) + g) * 4096;
-        const double *Ep = EI + (kk & 7) * 16 * C3_PLD;
-        if (wave >= 13 && wave - 13 < p) {
-          const int q = wave - 13;
-          c3_inverse_block(Lgk, Ep, EI + ((kk - p + q) & 7) * 16 * C3_PLD, p, q, l15, l4, o, ot);
-        }
-        if (wave == 11) {  // the diagonal block
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const int a = l4 + 4 * rr;
-            const double v = Ep[a * C3_PLD + l15];
-            o[(16 * p + a) * 64 + 16 * p + l15] = v;
-            ot[(16 * p + l15) * 64 + 16 * p + a] = v;
-          }
-        }
-      }
-      C3_OSTAMP(k == 2 || k == 13);
-    }
-    c3_barrier();
-    write_pivot_tile(nst - 1);
-  }
-#undef C3_STAMP
-#undef C3_OSTAMP
-}
