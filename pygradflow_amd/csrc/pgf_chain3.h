@@ -219,3 +219,423 @@ __device__ __forceinline__ void c3_inverse_block(double *Lg, const double *Ep, c
 //   Linv / LinvT  inverses of the unit-lower 64 x 64 diagonal tiles and their transposes
 //   dbg    optional phase stamps (wall clock; shader cycles 64 entries further): [0, 32)
 //          wavefront 0, [32, 64) wavefront 5
+__device__ __forceinline__ void chain3_body(unsigned char *smem, double *K, int64_t ldk, int c0, int nb,
+                                            double *__restrict__ dvec, double *__restrict__ dinv,
+                                            int *__restrict__ flags, double *__restrict__ Linv,
+                                            double *__restrict__ LinvT, long long *__restrict__ dbg) {
+  double *PT = reinterpret_cast<double *>(smem + C3_PT_OFF);
+  double *EI = reinterpret_cast<double *>(smem + C3_EI_OFF);  // [C3_NEI][16][18]
+  double *LK = reinterpret_cast<double *>(smem + C3_LK_OFF);  // [4][16][18]: -L_kk, D on the diagonal
+  double *Dl = reinterpret_cast<double *>(smem + C3_D_OFF);    // D [4][16], then 1/D [4][16]
+  int *stg = reinterpret_cast<int *>(smem + C3_D_OFF + 8 * 16 * 8);  // steps whose two tiles are parked
+  double *STB = reinterpret_cast<double *>(smem + C3_ST_OFF), *STC = STB + 256;
+  double *XW = reinterpret_cast<double *>(smem + C3_XW_OFF);  // [3][4][64]
+  double *XP = reinterpret_cast<double *>(smem + C3_XP_OFF);  // [2][16][4][64]
+  double *Lg = reinterpret_cast<double *>(smem + C3_LG_OFF);  // [2][12][16][18]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int bend = c0 + nb;
+  const int nst = (nb + 15) >> 4;  // 16-column steps
+  int dbi = 0;
+  (void)dbi;
+#ifdef C3_TIMING
+#define C3_STAMP()                     \
+  do {                                 \
+    if (dbg && tid == 0 && dbi < 32) { \
+      dbg[64 + dbi] = clock64();       \
+      dbg[dbi++] = wall_clock64();     \
+    }                                  \
+  } while (0)
+#else
+#define C3_STAMP() \
+  do {             \
+  } while (0)
+#endif
+  C3_STAMP();
+  int dbo = 32;
+  (void)dbo;
+#ifdef C3_TIMING
+#define C3_OSTAMP(cond)                                                       \
+  do {                                                                        \
+    if (dbg && tid == 320 && (cond) && dbo < 64) dbg[dbo++] = wall_clock64(); \
+  } while (0)
+#else
+#define C3_OSTAMP(cond) \
+  do {                  \
+  } while (0)
+#endif
+
+  // inv / inv^T of the block's 64 x 64 tiles: zeros above the diagonal, identity where a ragged
+  // last tile has no rows (everything else is written block by block as the chain advances)
+  for (int g = 0; g < (nb + 63) >> 6; ++g) {
+    double *o = Linv + (size_t)((c0 >> 6) + g) * 4096, *ot = LinvT + (size_t)((c0 >> 6) + g) * 4096;
+    for (int p = tid; p < 4096; p += 1024) {
+      const int rr = p >> 6, cc = p & 63;
+      const bool above = (cc >> 4) > (rr >> 4);
+      const bool norow = 64 * g + (rr & ~15) >= 16 * nst, nocol = 64 * g + (cc & ~15) >= 16 * nst;
+      if (above || norow) o[p] = (rr == cc) ? 1.0 : 0.0;
+      if ((rr >> 4) > (cc >> 4) || nocol) ot[p] = (rr == cc) ? 1.0 : 0.0;
+    }
+  }
+  if (tid == 0) *stg = 0;
+
+  // Three role loops with the same barrier sequence: the roles' register needs differ
+  // (elimination: two 16-entry rows; tile owners: twelve accumulators), and in one loop the
+  // compiler keeps all sets alive across each other's code and spills.
+  if (wave == 0) {
+    {
+      // pivot tile of step 0: from global memory (identity beyond the block's end) to where every
+      // step finds its tile
+      const int row = c0 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = c0 + l4 + 4 * r;
+        double v = (row == col) ? 1.0 : 0.0;
+        if (row < bend) v = (col <= row) ? K[(int64_t)row * ldk + col] : 0.0;
+        PT[l15 * C3_PLD + l4 + 4 * r] = v;
+      }
+    }
+    bool bad = false;
+    int neg = 0;
+    c3_barrier();
+    C3_STAMP();
+    for (int k = 0; k < nst; ++k) {
+      const int ncol = min(16, bend - (c0 + 16 * k));
+      double e[16], dsel[4] = {0.0, 0.0, 0.0, 0.0}, dmine;
+      {
+        // (lane indices laundered around the elimination: otherwise every LDS address of the
+        // step is computed up front and kept alive across it, where a lane has no register to
+        // spare, and spilled)
+        int ln = threadIdx.x;
+        asm volatile("" : "+v"(ln));
+        // the pivot tile, lane <-> row (from the MFMA layout through LDS; not carried in
+        // registers from the end of the previous step: the compiler then keeps two copies)
+        double a[16];
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+          const double2_t v = *reinterpret_cast<const double2_t *>(PT + (ln & 15) * C3_PLD + j);
+          a[j] = v.x;
+          a[j + 1] = v.y;
+        }
+        // (-L_kk goes to LDS column by column: a service wavefront takes it to global memory two
+        // steps on)
+        double *lkp = LK + ((k & 3) * 16 + (ln & 15)) * C3_PLD;
+        c3_eliminate(a, (unsigned)(uintptr_t)lkp, e, dmine, dsel, ln & 15, ln >> 4);
+        if (ln < 16) lkp[ln] = dmine;
+      }
+      if (k == 1 || k == 14) C3_STAMP();  // elimination
+      int ln = threadIdx.x;
+      asm volatile("" : "+v"(ln));
+      const int r15 = ln & 15, r4 = ln >> 4;
+      const double imine = fast_recip(dmine);
+      {
+        const bool mine = ln < 16 && r15 < ncol;
+        bad |= __ballot(mine && __builtin_amdgcn_class(dmine, C3_BAD_CLASS)) != 0ull;
+        neg += __popcll(__ballot(mine && dmine < 0.0));
+      }
+      // inv(L_kk) leaves the registers as the MFMA operand each lane needs of it -- entries
+      // (row, 4 s + its row of 16 lanes) -- and goes to LDS from all 64 lanes in that shape: four
+      // 8-byte stores instead of eight 16-byte stores of 16 lanes (an LDS store costs ~20 cycles
+      // per 8 bytes of a lane)
+      double as[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        as[s] = (r4 == 0) ? e[4 * s] : (r4 == 1) ? e[4 * s + 1] : (r4 == 2) ? e[4 * s + 2] : e[4 * s + 3];
+      double *ei = EI + ((k % C3_NEI) * 16 + r15) * C3_PLD + r4;
+      if (k + 1 < nst) {
+        // ---- panel tile (k + 1, k) and the next pivot tile (k + 1, k + 1), parked by their owner
+        for (int it = 0; it < (1 << 22) && c3_ld(stg) < k + 1; ++it) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        double bt[4];
+        double4_t x = (double4_t){0.0, 0.0, 0.0, 0.0}, t;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bt[s] = STB[64 * s + ln];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = STC[64 * r + ln];
+        // (what the owners wait for goes out while the matrix pipe works)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ei[4 * s] = as[s];
+        if (ln < 16) {
+          Dl[16 * (k & 3) + r15] = dmine;
+          Dl[64 + 16 * (k & 3) + r15] = imine;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) x = __builtin_amdgcn_mfma_f64_16x16x4f64(as[s], bt[s], x, 0, 0, 0);
+        // the panel tile is published as -L = -X D^-1: every live tile it meets lies below its
+        // tile row, where it is the scaled operand (and the write-back wants L)
+        double *xo = XW + (k % 3) * 256 + ln;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const double nls = -x[s] * dsel[s];
+          xo[64 * s] = nls;
+          t = __builtin_amdgcn_mfma_f64_16x16x4f64(nls, x[s], t, 0, 0, 0);
+        }
+        // next pivot tile: MFMA layout -> (next step) lane <-> row through LDS
+#pragma unroll
+        for (int r = 0; r < 4; ++r) PT[r15 * C3_PLD + r4 + 4 * r] = t[r];
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ei[4 * s] = as[s];
+        if (ln < 16) {
+          Dl[16 * (k & 3) + r15] = dmine;
+          Dl[64 + 16 * (k & 3) + r15] = imine;
+        }
+      }
+      if (k == 1 || k == 14) C3_STAMP();  // panel tile, next pivot tile
+      c3_barrier();  // step k is published: inv(L_kk), D, panel tile (k + 1, k), the factored tile
+      C3_STAMP();
+    }
+    c3_barrier();  // (the last write-back reads the last factored tile)
+    if (lane == 0) {
+      if (bad) atomicOr(&flags[0], 1);
+      if (neg) atomicAdd(&flags[1], neg);
+    }
+  } else if ((wave & 3) == 0) {
+    // ---- wavefronts 4, 8, 12: the write-backs (no FP64 arithmetic to speak of on wavefront 0's SIMD)
+    const int sv = (wave >> 2) - 1;  // 0, 1, 2: the tiles with tile row % 3 == sv
+    const int wr = lane >> 2, wc4 = lane & 3;
+    // 16 x 16 tile in MFMA-operand layout ([4][64] at xs, scaled by dsc[column] or negated) ->
+    // rows [row0, row0 + 16), columns [col0, col0 + 16) of K, four lanes per row
+    auto write_tile = [&](const double *xs, const double *dsc, int row0, int col0) {
+      const double *x4 = xs + wc4 * 64 + wr;
+      double2_t lo, hi;
+      lo.x = dsc ? x4[0] * dsc[4 * wc4] : -x4[0];
+      lo.y = dsc ? x4[16] * dsc[4 * wc4 + 1] : -x4[16];
+      hi.x = dsc ? x4[32] * dsc[4 * wc4 + 2] : -x4[32];
+      hi.y = dsc ? x4[48] * dsc[4 * wc4 + 3] : -x4[48];
+      if (row0 + wr < bend) {
+        double *dst = K + (int64_t)(row0 + wr) * ldk + col0 + 4 * wc4;
+        *reinterpret_cast<double2_t *>(dst) = lo;
+        *reinterpret_cast<double2_t *>(dst + 2) = hi;
+      }
+    };
+    // the factored pivot tile of step ks with D and 1 / D
+    auto write_pivot_tile = [&](int ks) {
+      const int row = c0 + 16 * ks + wr;
+      const double *lk = LK + ((ks & 3) * 16 + wr) * C3_PLD + 4 * wc4;
+      if (row < bend) {
+        double *dst = K + (int64_t)row * ldk + c0 + 16 * ks + 4 * wc4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (4 * wc4 + t <= wr) dst[t] = (4 * wc4 + t == wr) ? lk[t] : -lk[t];
+        if (wc4 == 0) {
+          dvec[row] = Dl[16 * (ks & 3) + wr];
+          dinv[row] = Dl[64 + 16 * (ks & 3) + wr];
+        }
+      }
+    };
+    c3_barrier();
+    for (int k = 1; k <= nst; ++k) {
+      c3_barrier();
+      const int kk = k - 1, kl = k - 2;
+      // panel tile (k, kk), wavefront 0's (-L): global memory, and its copy in the inverse workspace
+      if (k < nst && sv == kk % 3) {
+        const double *xw = XW + (kk % 3) * 256;
+        write_tile(xw, nullptr, c0 + 16 * k, c0 + 16 * kk);
+        if ((k >> 2) == (kk >> 2)) {
+          double *lb = c3_lblock(Lg + ((kk >> 2) & 1) * 12 * 16 * C3_PLD, k & 3, kk & 3) + l15 * C3_PLD + l4;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) lb[4 * s] = -xw[64 * s + lane];
+        }
+      }
+      // the owners' tiles of panel kl (complete since the last barrier; its buffer stays through
+      // this body), and the factored pivot tile of that step
+      if (kl >= 0) {
+        for (int it = k + sv; it < nst; it += 3)
+          write_tile(XP + (size_t)((kl & 1) * 4096 + it * 256), Dl + 64 + 16 * (kl & 3), c0 + 16 * it, c0 + 16 * kl);
+        if (sv == kl % 3) write_pivot_tile(kl);
+      }
+    }
+    c3_barrier();
+    if (sv == (nst - 1) % 3) write_pivot_tile(nst - 1);
+  } else {
+    // ---- the tile owners
+    const int oi = wave - 1 - (wave >> 2);
+    int ti[C3_NS], tl[C3_NS];
+    double4_t acc[C3_NS];
+#pragma unroll
+    for (int q = 0; q < C3_NS; ++q) {
+      const int v = c3_tab[oi][q];
+      ti[q] = ((v & 15) >= nst || (v >> 4) > (v & 15)) ? -1 : (v & 15);
+      tl[q] = v >> 4;
+    }
+#pragma unroll
+    for (int q = 0; q < C3_NS; ++q) {
+      acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      if (ti[q] >= 0) {
+        const int row = c0 + 16 * ti[q] + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = c0 + 16 * tl[q] + l4 + 4 * r;
+          double v = (row == col) ? 1.0 : 0.0;  // identity beyond the block's end
+          if (row < bend) v = (col <= row) ? K[(int64_t)row * ldk + col] : 0.0;
+          acc[q][r] = v;
+        }
+      }
+    }
+    // the two tiles wavefront 0 needs in step k -- T(k + 1, k) as the B operand of its panel
+    // product, pivot tile (k + 1, k + 1) as the accumulator of its update -- go to LDS
+    auto park = [&](int k) {
+      if (k + 1 >= nst) return;
+      bool mine = false;
+#pragma unroll
+      for (int q = 0; q < C3_NS; ++q) {
+        if (ti[q] == k + 1 && tl[q] == k) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) STB[64 * s + lane] = acc[q][s];
+          ti[q] = -1;
+          mine = true;
+        }
+        if (ti[q] == k + 1 && tl[q] == k + 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) STC[64 * r + lane] = acc[q][r];
+          ti[q] = -1;
+        }
+      }
+      if (mine) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(stg, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    };
+    park(0);
+    c3_barrier();
+    // Body k, beside wavefront 0's step k.  The rank-16 updates LAG one step: what body k applies
+    // to the bulk of the tiles is step k - 2, whose panel has been complete since the last
+    // barrier -- nobody waits for the panel of step kk = k - 1, which this body only writes.  Only
+    // the tiles about to turn into operands catch up first: tile column kk (the panel tiles of
+    // this body) and the band of tile row k + 1 (parked for wavefront 0).
+    for (int k = 1; k <= nst; ++k) {
+      c3_barrier();  // wavefront 0 has published step kk: inv(L_kk), D, panel tile (k, kk)
+      // (tile indices laundered per step: otherwise every LDS address of every slot is hoisted
+      // out of the loop and kept alive beside the accumulators)
+#pragma unroll
+      for (int q = 0; q < C3_NS; ++q) asm volatile("" : "+s"(ti[q]), "+s"(tl[q]));
+      const int kk = k - 1, kl = k - 2;
+      const double *xpl = XP + (size_t)((kl & 1) * 4096) + lane;  // panel kl (complete)
+      double *xpn = XP + (size_t)((kk & 1) * 4096) + lane;        // panel kk (this body writes it)
+      const double *xwl = XW + ((kl + 3) % 3) * 256 + lane;       // -L of panel tile (kk, kl)
+      const double *xwn = XW + (kk % 3) * 256 + lane;             // -L of panel tile (k, kk)
+      const double *ei = EI + ((kk % C3_NEI) * 16 + l15) * C3_PLD + l4;
+      const double *dil = Dl + 64 + 16 * (kl & 3) + l4, *din = Dl + 64 + 16 * (kk & 3) + l4;
+      double *Lgk = Lg + ((kk >> 2) & 1) * 12 * 16 * C3_PLD;
+      C3_OSTAMP(k == 2 || k == 13);
+      // step kl's update of tile q (tile rows >= k, tile columns >= kk; panel tile (kk, kl) is
+      // wavefront 0's and comes as -L: every live tile it meets has it on the column side).
+      // Two k-steps at a time: with all eight operands of a tile in flight at once the twelve
+      // accumulators do not fit the 128 registers of a lane.
+      auto update_lag = [&](int q) {
+        const double *xi = xpl + ti[q] * 256;
+        if (tl[q] == kk) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xwl[64 * s], xi[64 * s], acc[q], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int s = 2; s < 4; ++s)
+            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xwl[64 * s], xi[64 * s], acc[q], 0, 0, 0);
+        } else {
+          const double *xl = xpl + tl[q] * 256;
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xl[64 * s] * dil[4 * s], xi[64 * s], acc[q], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int s = 2; s < 4; ++s)
+            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xl[64 * s] * dil[4 * s], xi[64 * s], acc[q], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      // panel tile of slot q: X^T = inv(L_kk) T^T -> x (MFMA C layout = operand layout of the
+      // updates), panel buffer, inverse workspace
+      auto panel_tile = [&](int q, double4_t &x) {
+        x = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) x = __builtin_amdgcn_mfma_f64_16x16x4f64(ei[4 * s], acc[q][s], x, 0, 0, 0);
+        double *xo = xpn + ti[q] * 256;
+        const bool ingroup = (ti[q] >> 2) == (kk >> 2);
+        double *lb = c3_lblock(Lgk, ti[q] & 3, kk & 3) + l15 * C3_PLD + l4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          xo[64 * s] = x[s];
+          if (ingroup) lb[4 * s] = x[s] * din[4 * s];
+        }
+        ti[q] = -1;  // final
+      };
+      // ---- the band of tile row k + 1, if it is this wavefront's: catch up with step kl, panel
+      // tile (k + 1, kk), then from registers step kk's update of the two tiles wavefront 0
+      // takes over in step k
+      if (k + 1 < nst) {
+        bool band = false;
+#pragma unroll
+        for (int q = 0; q < C3_NS; ++q) {
+          if (ti[q] == k + 1 && tl[q] >= kk) {
+            if (kl >= 0) update_lag(q);
+            band = true;
+          }
+        }
+        if (band) {
+          double4_t xb = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int q = 0; q < C3_NS; ++q)
+            if (ti[q] == k + 1 && tl[q] == kk) panel_tile(q, xb);
+#pragma unroll
+          for (int q = 0; q < C3_NS; ++q) {
+            if (ti[q] == k + 1 && tl[q] == k) {
+#pragma unroll
+              for (int s = 0; s < 4; ++s)
+                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xwn[64 * s], xb[s], acc[q], 0, 0, 0);
+            }
+            if (ti[q] == k + 1 && tl[q] == k + 1) {
+#pragma unroll
+              for (int s = 0; s < 4; ++s)
+                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xb[s] * din[4 * s], xb[s], acc[q], 0, 0, 0);
+            }
+          }
+          park(k);
+        }
+      }
+      C3_OSTAMP(k == 2 || k == 13);
+      // ---- the rest of tile column kk: catch up, then the panel tile
+#pragma unroll
+      for (int q = 0; q < C3_NS; ++q) {
+        if (ti[q] > k && tl[q] == kk) {
+          if (kl >= 0) update_lag(q);
+          double4_t x;
+          panel_tile(q, x);
+        }
+      }
+      C3_OSTAMP(k == 2 || k == 13);
+      // ---- step kl's update of every other live tile
+      if (kl >= 0) {
+#pragma unroll
+        for (int q = 0; q < C3_NS; ++q)
+          if (ti[q] >= 0 && tl[q] > kk) update_lag(q);
+      }
+      C3_OSTAMP(k == 2 || k == 13);
+      // ---- block row kk & 3 of the group's 64 x 64 inverse: one wavefront per block
+      {
+        const int p = kk & 3, g = kk >> 2;
+        double *o = Linv + (size_t)((c0 >> 6) + g) * 4096, *ot = LinvT + (size_t)((c0 >> 6) + g) * 4096;
+        const double *Ep = EI + (kk % C3_NEI) * 16 * C3_PLD;
+        if (wave >= 13 && wave - 13 < p) {
+          const int q = wave - 13;
+          c3_inverse_block(Lgk, Ep, EI + ((kk - p + q) % C3_NEI) * 16 * C3_PLD, p, q, l15, l4, o, ot);
+        }
+        if (wave == 11) {  // the diagonal block
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int a = l4 + 4 * rr;
+            const double v = Ep[a * C3_PLD + l15];
+            o[(16 * p + a) * 64 + 16 * p + l15] = v;
+            ot[(16 * p + l15) * 64 + 16 * p + a] = v;
+          }
+        }
+      }
+      C3_OSTAMP(k == 2 || k == 13);
+    }
+    c3_barrier();
+  }
+#undef C3_STAMP
+#undef C3_OSTAMP
+}
