@@ -43,10 +43,10 @@
 #define C3_NEI 6                                     // inv(L_kk) of the last six steps
 #define C3_EI_OFF (C3_PT_OFF + 16 * C3_PLD * 8)      // [C3_NEI][16][18]
 #define C3_LK_OFF (C3_EI_OFF + C3_NEI * 16 * C3_PLD * 8)  // factored pivot tile [4][16][18]
-#define C3_D_OFF (C3_LK_OFF + 4 * 16 * C3_PLD * 8)   // D[4][16] | 1/D[4][16] | counters
-#define C3_ST_OFF (C3_D_OFF + 8 * 16 * 8 + 16)       // parked tiles: B operand [4][64] | C [4][64]
-#define C3_XW_OFF (C3_ST_OFF + 2 * 256 * 8)          // wavefront 0's panel tile, as -L [3][4][64]
-#define C3_XP_OFF (C3_XW_OFF + 3 * 256 * 8)          // X panels of two steps [2][16 tiles][4][64]
+#define C3_D_OFF (C3_LK_OFF + 4 * 16 * C3_PLD * 8)   // D[4][16] | 1/D[4][16] | 1/D as [4][row of lanes][k-step] | counters
+#define C3_ST_OFF (C3_D_OFF + 12 * 16 * 8 + 16)      // parked tiles: B operand [2][64][2] | C [2][64][2]
+#define C3_XW_OFF (C3_ST_OFF + 2 * 256 * 8)          // wavefront 0's panel tile, as -L [3][2][64][2]
+#define C3_XP_OFF (C3_XW_OFF + 3 * 256 * 8)          // X panels of two steps [2][16 tiles][2][64][2]
 #define C3_LG_OFF (C3_XP_OFF + 2 * 16 * 256 * 8)     // inverse workspace [2 groups][12 blocks][16][18]
 #define C3_SMEM (C3_LG_OFF + 2 * 12 * 16 * C3_PLD * 8)
 
@@ -227,7 +227,7 @@ __device__ __forceinline__ void chain3_body(unsigned char *smem, double *K, int6
   double *EI = reinterpret_cast<double *>(smem + C3_EI_OFF);  // [C3_NEI][16][18]
   double *LK = reinterpret_cast<double *>(smem + C3_LK_OFF);  // [4][16][18]: -L_kk, D on the diagonal
   double *Dl = reinterpret_cast<double *>(smem + C3_D_OFF);    // D [4][16], then 1/D [4][16]
-  int *stg = reinterpret_cast<int *>(smem + C3_D_OFF + 8 * 16 * 8);  // steps whose two tiles are parked
+  int *stg = reinterpret_cast<int *>(smem + C3_D_OFF + 12 * 16 * 8);  // steps whose two tiles are parked
   double *STB = reinterpret_cast<double *>(smem + C3_ST_OFF), *STC = STB + 256;
   double *XW = reinterpret_cast<double *>(smem + C3_XW_OFF);  // [3][4][64]
   double *XP = reinterpret_cast<double *>(smem + C3_XP_OFF);  // [2][16][4][64]
@@ -346,30 +346,41 @@ __device__ __forceinline__ void chain3_body(unsigned char *smem, double *K, int6
         // ---- panel tile (k + 1, k) and the next pivot tile (k + 1, k + 1), parked by their owner
         for (int it = 0; it < (1 << 22) && c3_ld(stg) < k + 1; ++it) __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
+        // (tiles in MFMA-operand layout live in LDS as [k-step pair][lane][2]: one 16-byte access
+        // per two k-steps -- LDS time, not the matrix pipe, bounds the owners' updates otherwise)
         double bt[4];
         double4_t x = (double4_t){0.0, 0.0, 0.0, 0.0}, t;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) bt[s] = STB[64 * s + ln];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) t[r] = STC[64 * r + ln];
+        for (int h = 0; h < 2; ++h) {
+          const double2_t b2 = *reinterpret_cast<const double2_t *>(STB + 128 * h + 2 * ln);
+          const double2_t c2 = *reinterpret_cast<const double2_t *>(STC + 128 * h + 2 * ln);
+          bt[2 * h] = b2.x;
+          bt[2 * h + 1] = b2.y;
+          t[2 * h] = c2.x;
+          t[2 * h + 1] = c2.y;
+        }
         // (what the owners wait for goes out while the matrix pipe works)
 #pragma unroll
         for (int s = 0; s < 4; ++s) ei[4 * s] = as[s];
         if (ln < 16) {
           Dl[16 * (k & 3) + r15] = dmine;
           Dl[64 + 16 * (k & 3) + r15] = imine;
+          Dl[128 + 16 * (k & 3) + 4 * (r15 & 3) + (r15 >> 2)] = imine;
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) x = __builtin_amdgcn_mfma_f64_16x16x4f64(as[s], bt[s], x, 0, 0, 0);
         // the panel tile is published as -L = -X D^-1: every live tile it meets lies below its
         // tile row, where it is the scaled operand (and the write-back wants L)
-        double *xo = XW + (k % 3) * 256 + ln;
+        double *xo = XW + (k % 3) * 256 + 2 * ln;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const double nls = -x[s] * dsel[s];
-          xo[64 * s] = nls;
-          t = __builtin_amdgcn_mfma_f64_16x16x4f64(nls, x[s], t, 0, 0, 0);
+        for (int h = 0; h < 2; ++h) {
+          double2_t nl2;
+          nl2.x = -x[2 * h] * dsel[2 * h];
+          nl2.y = -x[2 * h + 1] * dsel[2 * h + 1];
+          *reinterpret_cast<double2_t *>(xo + 128 * h) = nl2;
+          t = __builtin_amdgcn_mfma_f64_16x16x4f64(nl2.x, x[2 * h], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f64_16x16x4f64(nl2.y, x[2 * h + 1], t, 0, 0, 0);
         }
         // next pivot tile: MFMA layout -> (next step) lane <-> row through LDS
 #pragma unroll
@@ -380,6 +391,7 @@ __device__ __forceinline__ void chain3_body(unsigned char *smem, double *K, int6
         if (ln < 16) {
           Dl[16 * (k & 3) + r15] = dmine;
           Dl[64 + 16 * (k & 3) + r15] = imine;
+          Dl[128 + 16 * (k & 3) + 4 * (r15 & 3) + (r15 >> 2)] = imine;
         }
       }
       if (k == 1 || k == 14) C3_STAMP();  // panel tile, next pivot tile
@@ -398,12 +410,12 @@ __device__ __forceinline__ void chain3_body(unsigned char *smem, double *K, int6
     // 16 x 16 tile in MFMA-operand layout ([4][64] at xs, scaled by dsc[column] or negated) ->
     // rows [row0, row0 + 16), columns [col0, col0 + 16) of K, four lanes per row
     auto write_tile = [&](const double *xs, const double *dsc, int row0, int col0) {
-      const double *x4 = xs + wc4 * 64 + wr;
+      const double *x4 = xs + (wc4 >> 1) * 128 + 2 * wr + (wc4 & 1);  // entry (k-step wc4, lane t * 16 + wr)
       double2_t lo, hi;
       lo.x = dsc ? x4[0] * dsc[4 * wc4] : -x4[0];
-      lo.y = dsc ? x4[16] * dsc[4 * wc4 + 1] : -x4[16];
-      hi.x = dsc ? x4[32] * dsc[4 * wc4 + 2] : -x4[32];
-      hi.y = dsc ? x4[48] * dsc[4 * wc4 + 3] : -x4[48];
+      lo.y = dsc ? x4[32] * dsc[4 * wc4 + 1] : -x4[32];
+      hi.x = dsc ? x4[64] * dsc[4 * wc4 + 2] : -x4[64];
+      hi.y = dsc ? x4[96] * dsc[4 * wc4 + 3] : -x4[96];
       if (row0 + wr < bend) {
         double *dst = K + (int64_t)(row0 + wr) * ldk + col0 + 4 * wc4;
         *reinterpret_cast<double2_t *>(dst) = lo;
@@ -436,7 +448,7 @@ __device__ __forceinline__ void chain3_body(unsigned char *smem, double *K, int6
         if ((k >> 2) == (kk >> 2)) {
           double *lb = c3_lblock(Lg + ((kk >> 2) & 1) * 12 * 16 * C3_PLD, k & 3, kk & 3) + l15 * C3_PLD + l4;
 #pragma unroll
-          for (int s = 0; s < 4; ++s) lb[4 * s] = -xw[64 * s + lane];
+          for (int s = 0; s < 4; ++s) lb[4 * s] = -xw[(s >> 1) * 128 + 2 * lane + (s & 1)];
         }
       }
       // the owners' tiles of panel kl (complete since the last barrier; its buffer stays through
@@ -483,13 +495,15 @@ __device__ __forceinline__ void chain3_body(unsigned char *smem, double *K, int6
       for (int q = 0; q < C3_NS; ++q) {
         if (ti[q] == k + 1 && tl[q] == k) {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) STB[64 * s + lane] = acc[q][s];
+          for (int h = 0; h < 2; ++h)
+            *reinterpret_cast<double2_t *>(STB + 128 * h + 2 * lane) = (double2_t){acc[q][2 * h], acc[q][2 * h + 1]};
           ti[q] = -1;
           mine = true;
         }
         if (ti[q] == k + 1 && tl[q] == k + 1) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) STC[64 * r + lane] = acc[q][r];
+          for (int h = 0; h < 2; ++h)
+            *reinterpret_cast<double2_t *>(STC + 128 * h + 2 * lane) = (double2_t){acc[q][2 * h], acc[q][2 * h + 1]};
           ti[q] = -1;
         }
       }
@@ -512,12 +526,15 @@ __device__ __forceinline__ void chain3_body(unsigned char *smem, double *K, int6
 #pragma unroll
       for (int q = 0; q < C3_NS; ++q) asm volatile("" : "+s"(ti[q]), "+s"(tl[q]));
       const int kk = k - 1, kl = k - 2;
-      const double *xpl = XP + (size_t)((kl & 1) * 4096) + lane;  // panel kl (complete)
-      double *xpn = XP + (size_t)((kk & 1) * 4096) + lane;        // panel kk (this body writes it)
-      const double *xwl = XW + ((kl + 3) % 3) * 256 + lane;       // -L of panel tile (kk, kl)
-      const double *xwn = XW + (kk % 3) * 256 + lane;             // -L of panel tile (k, kk)
+      const double *xpl = XP + (size_t)((kl & 1) * 4096) + 2 * lane;  // panel kl (complete)
+      double *xpn = XP + (size_t)((kk & 1) * 4096) + 2 * lane;        // panel kk (this body writes it)
+      const double *xwl = XW + ((kl + 3) % 3) * 256 + 2 * lane;       // -L of panel tile (kk, kl)
+      const double *xwn = XW + (kk % 3) * 256 + 2 * lane;             // -L of panel tile (k, kk)
       const double *ei = EI + ((kk % C3_NEI) * 16 + l15) * C3_PLD + l4;
-      const double *dil = Dl + 64 + 16 * (kl & 3) + l4, *din = Dl + 64 + 16 * (kk & 3) + l4;
+      const double *din = Dl + 128 + 16 * (kk & 3) + 4 * l4;  // 1 / D of step kk, this lane's four
+      double2_t dql[2];                                       // 1 / D of step kl, this lane's four
+      dql[0] = *reinterpret_cast<const double2_t *>(Dl + 128 + 16 * (kl & 3) + 4 * l4);
+      dql[1] = *reinterpret_cast<const double2_t *>(Dl + 128 + 16 * (kl & 3) + 4 * l4 + 2);
       double *Lgk = Lg + ((kk >> 2) & 1) * 12 * 16 * C3_PLD;
       C3_OSTAMP(k == 2 || k == 13);
       // step kl's update of tile q (tile rows >= k, tile columns >= kk; panel tile (kk, kl) is
@@ -526,25 +543,17 @@ __device__ __forceinline__ void chain3_body(unsigned char *smem, double *K, int6
       // accumulators do not fit the 128 registers of a lane.
       auto update_lag = [&](int q) {
         const double *xi = xpl + ti[q] * 256;
-        if (tl[q] == kk) {
+        const double *xl = (tl[q] == kk) ? xwl : xpl + tl[q] * 256;
+        const bool scale = tl[q] != kk;
 #pragma unroll
-          for (int s = 0; s < 2; ++s)
-            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xwl[64 * s], xi[64 * s], acc[q], 0, 0, 0);
+        for (int h = 0; h < 2; ++h) {
+          const double2_t b2 = *reinterpret_cast<const double2_t *>(xi + 128 * h);
+          double2_t a2 = *reinterpret_cast<const double2_t *>(xl + 128 * h);
+          if (scale) a2 = -a2 * dql[h];
+          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.x, acc[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.y, acc[q], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int s = 2; s < 4; ++s)
-            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xwl[64 * s], xi[64 * s], acc[q], 0, 0, 0);
-        } else {
-          const double *xl = xpl + tl[q] * 256;
-#pragma unroll
-          for (int s = 0; s < 2; ++s)
-            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xl[64 * s] * dil[4 * s], xi[64 * s], acc[q], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int s = 2; s < 4; ++s)
-            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xl[64 * s] * dil[4 * s], xi[64 * s], acc[q], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
       };
       // panel tile of slot q: X^T = inv(L_kk) T^T -> x (MFMA C layout = operand layout of the
       // updates), panel buffer, inverse workspace
@@ -556,9 +565,10 @@ __device__ __forceinline__ void chain3_body(unsigned char *smem, double *K, int6
         const bool ingroup = (ti[q] >> 2) == (kk >> 2);
         double *lb = c3_lblock(Lgk, ti[q] & 3, kk & 3) + l15 * C3_PLD + l4;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          xo[64 * s] = x[s];
-          if (ingroup) lb[4 * s] = x[s] * din[4 * s];
+        for (int h = 0; h < 2; ++h) *reinterpret_cast<double2_t *>(xo + 128 * h) = (double2_t){x[2 * h], x[2 * h + 1]};
+        if (ingroup) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) lb[4 * s] = x[s] * din[s];
         }
         ti[q] = -1;  // final
       };
@@ -584,12 +594,12 @@ __device__ __forceinline__ void chain3_body(unsigned char *smem, double *K, int6
             if (ti[q] == k + 1 && tl[q] == k) {
 #pragma unroll
               for (int s = 0; s < 4; ++s)
-                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xwn[64 * s], xb[s], acc[q], 0, 0, 0);
+                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xwn[(s >> 1) * 128 + (s & 1)], xb[s], acc[q], 0, 0, 0);
             }
             if (ti[q] == k + 1 && tl[q] == k + 1) {
 #pragma unroll
               for (int s = 0; s < 4; ++s)
-                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xb[s] * din[4 * s], xb[s], acc[q], 0, 0, 0);
+                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xb[s] * din[s], xb[s], acc[q], 0, 0, 0);
             }
           }
           park(k);
