@@ -265,16 +265,16 @@ __device__ __forceinline__ void chain3_body(unsigned char *smem, double *K, int6
   } while (0)
 #endif
 
-  // inv / inv^T of the block's 64 x 64 tiles: zeros above the diagonal, identity where a ragged
-  // last tile has no rows (everything else is written block by block as the chain advances)
-  for (int g = 0; g < (nb + 63) >> 6; ++g) {
+  // inv / inv^T of the block's 64 x 64 tiles are written block row by block row as the chain
+  // advances (zeros above the diagonal included); where a ragged last tile has no block rows:
+  // identity, here
+  if (nst & 3) {
+    const int g = (nb - 1) >> 6;
     double *o = Linv + (size_t)((c0 >> 6) + g) * 4096, *ot = LinvT + (size_t)((c0 >> 6) + g) * 4096;
     for (int p = tid; p < 4096; p += 1024) {
       const int rr = p >> 6, cc = p & 63;
-      const bool above = (cc >> 4) > (rr >> 4);
-      const bool norow = 64 * g + (rr & ~15) >= 16 * nst, nocol = 64 * g + (cc & ~15) >= 16 * nst;
-      if (above || norow) o[p] = (rr == cc) ? 1.0 : 0.0;
-      if ((rr >> 4) > (cc >> 4) || nocol) ot[p] = (rr == cc) ? 1.0 : 0.0;
+      if ((rr >> 4) >= (nst & 3)) o[p] = (rr == cc) ? 1.0 : 0.0;
+      if ((cc >> 4) >= (nst & 3)) ot[p] = (rr == cc) ? 1.0 : 0.0;
     }
   }
   if (tid == 0) *stg = 0;
@@ -287,12 +287,12 @@ __device__ __forceinline__ void chain3_body(unsigned char *smem, double *K, int6
       // pivot tile of step 0: from global memory (identity beyond the block's end) to where every
       // step finds its tile
       const int row = c0 + l15;
+      const double *src = K + (int64_t)min(row, bend - 1) * ldk + c0 + l4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int col = c0 + l4 + 4 * r;
-        double v = (row == col) ? 1.0 : 0.0;
-        if (row < bend) v = (col <= row) ? K[(int64_t)row * ldk + col] : 0.0;
-        PT[l15 * C3_PLD + l4 + 4 * r] = v;
+        const double v = src[4 * r];
+        PT[l15 * C3_PLD + l4 + 4 * r] = (row < bend) ? ((col <= row) ? v : 0.0) : ((row == col) ? 1.0 : 0.0);
       }
     }
     bool bad = false;
@@ -477,12 +477,14 @@ __device__ __forceinline__ void chain3_body(unsigned char *smem, double *K, int6
       acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
       if (ti[q] >= 0) {
         const int row = c0 + 16 * ti[q] + l15;
+        // (loads unconditional, from a clamped row: predicated, every one of them waits for the
+        // one before; what they fetch above the diagonal or beyond the block's end is replaced)
+        const double *src = K + (int64_t)min(row, bend - 1) * ldk + c0 + 16 * tl[q] + l4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int col = c0 + 16 * tl[q] + l4 + 4 * r;
-          double v = (row == col) ? 1.0 : 0.0;  // identity beyond the block's end
-          if (row < bend) v = (col <= row) ? K[(int64_t)row * ldk + col] : 0.0;
-          acc[q][r] = v;
+          const double v = src[4 * r];
+          acc[q][r] = (row < bend) ? ((col <= row) ? v : 0.0) : ((row == col) ? 1.0 : 0.0);  // identity beyond the end
         }
       }
     }
@@ -532,9 +534,7 @@ __device__ __forceinline__ void chain3_body(unsigned char *smem, double *K, int6
       const double *xwn = XW + (kk % 3) * 256 + 2 * lane;             // -L of panel tile (k, kk)
       const double *ei = EI + ((kk % C3_NEI) * 16 + l15) * C3_PLD + l4;
       const double *din = Dl + 128 + 16 * (kk & 3) + 4 * l4;  // 1 / D of step kk, this lane's four
-      double2_t dql[2];                                       // 1 / D of step kl, this lane's four
-      dql[0] = *reinterpret_cast<const double2_t *>(Dl + 128 + 16 * (kl & 3) + 4 * l4);
-      dql[1] = *reinterpret_cast<const double2_t *>(Dl + 128 + 16 * (kl & 3) + 4 * l4 + 2);
+      const double *dil = Dl + 128 + 16 * (kl & 3) + 4 * l4;  // 1 / D of step kl, this lane's four
       double *Lgk = Lg + ((kk >> 2) & 1) * 12 * 16 * C3_PLD;
       C3_OSTAMP(k == 2 || k == 13);
       // step kl's update of tile q (tile rows >= k, tile columns >= kk; panel tile (kk, kl) is
@@ -549,7 +549,7 @@ __device__ __forceinline__ void chain3_body(unsigned char *smem, double *K, int6
         for (int h = 0; h < 2; ++h) {
           const double2_t b2 = *reinterpret_cast<const double2_t *>(xi + 128 * h);
           double2_t a2 = *reinterpret_cast<const double2_t *>(xl + 128 * h);
-          if (scale) a2 = -a2 * dql[h];
+          if (scale) a2 = -a2 * *reinterpret_cast<const double2_t *>(dil + 2 * h);
           acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.x, acc[q], 0, 0, 0);
           acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.y, acc[q], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
@@ -632,13 +632,17 @@ __device__ __forceinline__ void chain3_body(unsigned char *smem, double *K, int6
           const int q = wave - 13;
           c3_inverse_block(Lgk, Ep, EI + ((kk - p + q) % C3_NEI) * 16 * C3_PLD, p, q, l15, l4, o, ot);
         }
-        if (wave == 11) {  // the diagonal block
+        if (wave == 11) {  // the diagonal block, and the zero blocks to its right
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
             const int a = l4 + 4 * rr;
             const double v = Ep[a * C3_PLD + l15];
             o[(16 * p + a) * 64 + 16 * p + l15] = v;
             ot[(16 * p + l15) * 64 + 16 * p + a] = v;
+            for (int q = p + 1; q < 4; ++q) {
+              o[(16 * p + a) * 64 + 16 * q + l15] = 0.0;
+              ot[(16 * q + l15) * 64 + 16 * p + a] = 0.0;
+            }
           }
         }
       }
