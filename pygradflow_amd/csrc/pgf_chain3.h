@@ -409,7 +409,7 @@ __device__ __forceinline__ void chain3_body(unsigned char *smem, double *K, int6
     const int wr = lane >> 2, wc4 = lane & 3;
     // 16 x 16 tile in MFMA-operand layout ([4][64] at xs, scaled by dsc[column] or negated) ->
     // rows [row0, row0 + 16), columns [col0, col0 + 16) of K, four lanes per row
-    auto write_tile = [&](const double *xs, const double *dsc, int row0, int col0) {
+    auto write_tile = [&](const double *xs, const double *dsc, int row0, int col0) __attribute__((always_inline)) {
       const double *x4 = xs + (wc4 >> 1) * 128 + 2 * wr + (wc4 & 1);  // entry (k-step wc4, lane t * 16 + wr)
       double2_t lo, hi;
       lo.x = dsc ? x4[0] * dsc[4 * wc4] : -x4[0];
@@ -423,7 +423,7 @@ __device__ __forceinline__ void chain3_body(unsigned char *smem, double *K, int6
       }
     };
     // the factored pivot tile of step ks with D and 1 / D
-    auto write_pivot_tile = [&](int ks) {
+    auto write_pivot_tile = [&](int ks) __attribute__((always_inline)) {
       const int row = c0 + 16 * ks + wr;
       const double *lk = LK + ((ks & 3) * 16 + wr) * C3_PLD + 4 * wc4;
       if (row < bend) {
@@ -490,7 +490,7 @@ __device__ __forceinline__ void chain3_body(unsigned char *smem, double *K, int6
     }
     // the two tiles wavefront 0 needs in step k -- T(k + 1, k) as the B operand of its panel
     // product, pivot tile (k + 1, k + 1) as the accumulator of its update -- go to LDS
-    auto park = [&](int k) {
+    auto park = [&](int k) __attribute__((always_inline)) {
       if (k + 1 >= nst) return;
       bool mine = false;
 #pragma unroll
@@ -541,7 +541,7 @@ __device__ __forceinline__ void chain3_body(unsigned char *smem, double *K, int6
       // wavefront 0's and comes as -L: every live tile it meets has it on the column side).
       // Two k-steps at a time: with all eight operands of a tile in flight at once the twelve
       // accumulators do not fit the 128 registers of a lane.
-      auto update_lag = [&](int q) {
+      auto update_lag = [&](int q) __attribute__((always_inline)) {
         const double *xi = xpl + ti[q] * 256;
         const double *xl = (tl[q] == kk) ? xwl : xpl + tl[q] * 256;
         const bool scale = tl[q] != kk;
@@ -557,7 +557,7 @@ __device__ __forceinline__ void chain3_body(unsigned char *smem, double *K, int6
       };
       // panel tile of slot q: X^T = inv(L_kk) T^T -> x (MFMA C layout = operand layout of the
       // updates), panel buffer, inverse workspace
-      auto panel_tile = [&](int q, double4_t &x) {
+      auto panel_tile = [&](int q, double4_t &x) __attribute__((always_inline)) {
         x = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int s = 0; s < 4; ++s) x = __builtin_amdgcn_mfma_f64_16x16x4f64(ei[4 * s], acc[q][s], x, 0, 0, 0);

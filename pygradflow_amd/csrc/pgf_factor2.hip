@@ -37,6 +37,7 @@
 
 #include "pgf_internal.h"
 #include "pgf_ldlt_dev.h"
+#include "pgf_chain3.h"
 
 #include <algorithm>
 #include <atomic>
@@ -1403,6 +1404,25 @@ __global__ __launch_bounds__(1024) void k_update_jobs(double *K, int64_t ldk,
 // batch_decode (T); every instance has its own N on the device, workgroups beyond it return.
 // The chain runs WITHOUT helper workgroups here: with hundreds of instances there is one
 // chain per CU and a spinning helper could wait for a CU its own chain occupies.
+// ---- the register-resident chain (pgf_chain3.h; PGF_CHAIN=3): no helper workgroups
+static_assert(C3_SMEM <= CH_SMEM, "chain3 LDS footprint");
+// (ONE kernel for the chain alone -- an empty job table -- and beside update tiles: with two
+// kernels inlining chain3_body in one translation unit the compiler spills 58 registers in each,
+// with one 5)
+__global__ __launch_bounds__(1024) void k_chain3_update(double *K, int64_t ldk, int c0, int nb,
+                                                        double *__restrict__ dvec, double *__restrict__ dinv,
+                                                        int *__restrict__ flags, double *__restrict__ Linv,
+                                                        double *__restrict__ LinvT, int N, int nrows,
+                                                        const UpdJobs jobs) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[CH_SMEM];
+  const int b = (int)blockIdx.x;
+  if (b == 0) {
+    chain3_body(smem, K, ldk, c0, nb, dvec, dinv, flags, Linv, LinvT, nullptr);
+    return;
+  }
+  update_job_tile(smem, b - 1, K, ldk, dvec, N, nrows, jobs);
+}
+
 template <bool HELP>
 __global__ __launch_bounds__(1024) void kb_diag_chain(const BInst *__restrict__ tab, int B, int Bp, int m,
                                                       int c0, int epoch) {
@@ -1526,6 +1546,12 @@ void ldlt_batch_launch_trsm(hipStream_t s, const BInst *tab, int B, int per, int
 // ------------------------------------------------------------------ host schedule
 bool ldlt_use_lookahead() {
   static const bool on = !(getenv("PGF_FACTOR") && atoi(getenv("PGF_FACTOR")) == 1);
+  return on;
+}
+
+// PGF_CHAIN=3: the register-resident chain of pgf_chain3.h instead of the LDS-panel chain
+static bool chain3_on() {
+  static const bool on = getenv("PGF_CHAIN") && atoi(getenv("PGF_CHAIN")) == 3;
   return on;
 }
 
@@ -1731,7 +1757,13 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
     long long *dbg = (c0 == 0) ? chain_dbg_buffer() : nullptr;
     const int nb = std::min(OB, N - c0);
     const int ep = next_help_epoch();
-    if (chain_waves() == 16) {
+    if (chain3_on()) {
+      UpdJobs none;
+      none.njobs = 0;
+      none.tile_begin[0] = 0;
+      hipLaunchKernelGGL(k_chain3_update, dim3(1), dim3(1024), 0, s, f.K, f.ldk, c0, nb, f.dvec, f.dinv,
+                         f.flags, f.Linv, f.LinvT, N, nrows, none);
+    } else if (chain_waves() == 16) {
       if (help)
         hipLaunchKernelGGL((k_diag_chain<16, true>), dim3(17), dim3(1024), 0, s, f.K, f.ldk, c0, nb,
                            f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, dbg, f.hctl, ep);
@@ -1836,7 +1868,10 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
       const UpdJobs &js = plan.launch[c0 / OB];
       const int ntiles = js.tile_begin[js.njobs];
       const int ep = next_help_epoch();
-      if (help)
+      if (chain3_on())
+        hipLaunchKernelGGL(k_chain3_update, dim3(1 + ntiles), dim3(1024), 0, s, f.K, f.ldk, c1, nb1,
+                           f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, N, nrows, js);
+      else if (help)
         hipLaunchKernelGGL(k_chain_update<true>, dim3(std::max(17, ntiles + 3)), dim3(1024), 0, s,
                            f.K, f.ldk, c1, nb1, f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, f.hctl, ep,
                            N, nrows, js);

@@ -22,6 +22,7 @@ VARIANTS = {
     "tight_update_budget": {"PGF_LAZY_BUDGET": "40", "PGF_LAZY_CAP": "1"},
     "legacy_schedule": {"PGF_FACTOR": "1"},
     "solves_per_super_block": {"PGF_TRSV_CHAIN": "0"},
+    "register_resident_chain": {"PGF_CHAIN": "3"},  # csrc/pgf_chain3.h (experimental, not the default)
 }
 
 
