@@ -14,10 +14,14 @@ N > 1: one process per GPU (launched by torch.distributed.run); each rank owns a
 independent instance of the same size (seed = rank): weak scaling over instances, and
 per step ONE RCCL all-gather of the ranks' residual norms ||F(z)||_2.
 
-Prints one JSON line (rank 0) with `roofline` (dominant kernel = the FP64-MFMA trailing
-update of the factorisation, timed with HIP events on the solver's stream in a separate
-instrumented pass over the same steps) and `cpu_baseline` (the numpy/scipy restatement
-of the reference path, oracle/, timed on the host cores; kind "port").
+Prints one JSON line (rank 0) with `roofline` (dominant launch = k_chain_update, the
+diagonal chain beside the FP64-MFMA trailing update, timed with HIP events on the solver's
+stream around the PRODUCTION launches in an instrumented pass over the same steps; the
+per-kernel view of the unfused schedule rides along under its own key) and `cpu_baseline`
+(the numpy/scipy restatement of the reference path, oracle/, timed on the host cores; kind
+"port").  At --gpus 1 the line also carries BASELINE configs[3] on one GPU (`batch256`: all
+256 instances; `shard32`: the 32 instances one rank of an 8-GPU run holds) and `plugin_step`:
+the drop-in path (HipStepSolver under newton_method, host callbacks, PCIe uploads).
 """
 
 import argparse
@@ -189,15 +193,15 @@ def bench_batched(args, wl, rank, local_rank, world, dist, torch, emit=True, ste
     if rank == 0:
         assert norms.numel() == B
         record = {
-            "metric": "Newton steps/sec on dense KKT n=1024 m=256, batch of 256 instances",
+            "metric": f"Newton steps/sec on dense KKT n={n} m={m}, batch of {B} instances",
             "value": nsteps * B / elapsed, "unit": "instance Newton steps/s",
             "n_gpus": world, "steps": nsteps, "warmup": nwarm,
             "ms_per_step": 1e3 * elapsed / nsteps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "batch256_n1024_m256", "n": n, "m": m, "instances": B,
+            "config": {"workload": f"batch{B}_n{n}_m{m}", "n": n, "m": m, "instances": B,
                        "instances_per_gpu": bd.hi - bd.lo, "newton_type": "Full",
                        "path": "device batch (pgf_batch_*, instance = XCD-pinned workgroup range)",
-                       "collective": "all_gather(256 residual norms)" if world > 1 else "none"},
+                       "collective": f"all_gather({B} residual norms)" if world > 1 else "none"},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         }
     bd.close()
@@ -209,14 +213,76 @@ def bench_batched(args, wl, rank, local_rank, world, dist, torch, emit=True, ste
         dist.destroy_process_group()
 
 
+def bench_plugin(problem, x0, y0, device, steps=6):
+    """The drop-in path at config 2: the reference's own hook, Params(step_solver=HipStepSolver)
+    (params.py:234, step/solver/__init__.py:18-19), driven by newton_method / FullNewtonMethod
+    (newton.py:63-89): g, c, the derivatives and the active set come from HOST callbacks every
+    step, H and J cross PCIe whenever update_derivs sees new matrices.  ms per Full Newton step:
+      constant_derivs   linear-quadratic problem, H / J uploaded once and kept resident
+      dense_upload      the same matrices treated as fresh every step (168 MB over PCIe per step)
+      csr_upload        a 1 %-dense sparse H and J: 12 bytes per stored entry, densified on the device
+    """
+    import scipy.sparse as sps
+
+    import pygradflow_amd as pgf
+    from pygradflow_amd import problems
+
+    n, m = problem.num_vars, problem.num_cons
+
+    def run(prob, label):
+        params = pgf.Params(newton_type="Full", step_solver=pgf.HipStepSolver)
+        orig = pgf.Iterate(prob, params, x0, y0)
+        method = pgf.newton_method(prob, params, orig, 1.0, 1.0)
+        it = orig
+        res = method.step(it)  # warm-up: first upload, allocations
+        it = res.iterate
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = method.step(it)
+            it = res.iterate
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        try:
+            method.step_solver.close()
+        except Exception:
+            pass
+        return dict(ms_per_step=ms, steps=steps, what=label)
+
+    out = {}
+    try:
+        out["constant_derivs"] = run(problem, "H, J resident in HBM after the first step; per step: host "
+                                              "g = Qx+q+A'(rho c+y), c = Ax-b, mask and vectors over PCIe")
+        fresh = problems.LinearQuadraticProblem(problem.Q, problem.q, problem.A, problem.b,
+                                                problem.var_lb, problem.var_ub)
+        fresh.pgf_constant_derivs = False
+        out["dense_upload"] = run(fresh, f"dense H ({8e-6 * n * n:.0f} MB) and J ({8e-6 * n * m:.0f} MB) "
+                                         "uploaded every step (pgf_set_derivs_dense)")
+        rng = np.random.default_rng(7)
+        Qs = sps.random(n, n, density=0.005, random_state=rng, format="csr")
+        Qs = (Qs + Qs.T + 4.0 * sps.identity(n)).tocsr()
+        As = sps.random(m, n, density=0.01, random_state=rng, format="csr")
+        sp = problems.LinearQuadraticProblem(Qs, problem.q, As, problem.b, problem.var_lb, problem.var_ub)
+        sp.pgf_constant_derivs = False
+        out["csr_upload"] = run(sp, f"sparse H ({Qs.nnz} entries, {100.0 * Qs.nnz / (n * n):.1f} %) and J "
+                                    f"({As.nnz}) uploaded as CSR every step (pgf_set_derivs_csr), "
+                                    "densified on the device")
+    except Exception as e:  # the headline record stays valid without this extra
+        out["error"] = f"{type(e).__name__}: {str(e)[:200]}"
+    out["note"] = ("HipStepSolver under newton_method: the reference's plug-in boundary; host "
+                   "evaluation and PCIe are inside these times, unlike `value`")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="dense_qp_n4096_m1024", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the nested records of the default workload at --gpus 1 "
+                         "(batch256, shard32, plugin_step)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -388,9 +454,15 @@ def main():
             # extract + log2(N/8) invert/reduce levels + the back-substitution levels); the
             # "flops" slot of the profile carries its algorithmic bytes
             gbs = pr["update_flops"] / (pr["update_ms"] * 1e-3) / 1e9
-            # algorithmic bytes of one STEP (K as CSR read + factors written +
-            # read twice + ~12 vector passes): 43 MB for config 3, ~3 MB for config 5
-            step_bytes = 3.0e6 if wl.get("box") else 43.0e6
+            # algorithmic bytes of one STEP, from the workload itself: H and J as
+            # CSR read once (12 bytes per stored entry), the band of the permuted KKT matrix
+            # ((bw + 1) doubles per row) written once and read twice, ~12 vector passes
+            # (43 MB for config 3, 3 MB for config 5 at their BASELINE sizes)
+            Hs, Js = problem.hess_sparse(), problem.jac_sparse()
+            bw = int(getattr(getattr(dn._hd, "plan", None), "bw", 1))
+            Nk = n + m
+            step_bytes = (12.0 * (Hs.nnz + (Js.nnz if m else 0)) + 3.0 * 8.0 * Nk * (bw + 1)
+                          + 12.0 * 8.0 * Nk)
             step_gbs = step_bytes * (args.steps / elapsed) / 1e9
             roof = dict(bound="hbm", kernel="bcr_solve (k_bcr_extract/invert/reduce/back)",
                         achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS,
@@ -402,27 +474,57 @@ def main():
                         note="~2 log2(N/8) dependent launches of a few microseconds each: "
                              "launch/latency-bound, not bandwidth-bound, at this size")
         elif pr["update_launches"] > 0 and pr["update_ms"] > 0:
-            achieved = pr["update_flops"] / (pr["update_ms"] * 1e-3) / 1e12
-            traffic = (pmc_traffic("k_update_jobs")
-                       if args.workload == "dense_qp_n4096_m1024" else None)
-            alg_bytes = pr["update_bytes"] / pr["update_launches"]
+            # per-kernel view: the UNFUSED schedule of an instrumented pass (diagonal chain and
+            # trailing update as separate launches, HIP events around each)
+            achieved_u = pr["update_flops"] / (pr["update_ms"] * 1e-3) / 1e12
+            unfused = dict(
+                kernel="k_update_jobs (= update role of k_chain_update as its own launch)",
+                achieved=achieved_u, frac=achieved_u / PEAK_FP64_MFMA_TFLOPS,
+                launches_per_step=pr["update_launches"] / args.steps,
+                avg_launch_us=1e3 * pr["update_ms"] / pr["update_launches"],
+                factor_ms_per_step=pr["factor_ms"] / args.steps,
+                kernel_ms_per_step={"k_diag_chain": pr["chain_ms"] / args.steps,
+                                    "k_update_jobs": pr["update_ms"] / args.steps,
+                                    "k_trsm_block": pr["trsm_ms"] / args.steps,
+                                    "k_update_diag": pr["udiag_ms"] / args.steps},
+                note=("NOT the timed schedule: the factorisation's kernels as separate launches "
+                      "with HIP events around them; in the timed region the diagonal chain and "
+                      "the trailing update share one launch (k_chain_update: same tile code, "
+                      "same job table), T(k) and the next diagonal block's update another "
+                      "(k_trsm_ud)"))
+            # the PRODUCTION launches: a second instrumented pass, one span per launch
+            dn.set_outer(x0, y0, 1.0, 1.0)
+            dn.profile(2)
+            for i in range(args.steps):
+                one_step(i)
+            pp = dn.profile_read()
+            dn.profile(False)
+            fused_ok = pp["fused_launches"] > 0 and pp["fused_ms"] > 0
+            achieved = (pp["fused_flops"] / (pp["fused_ms"] * 1e-3) / 1e12) if fused_ok else achieved_u
+            traffic = (pmc_traffic("k_chain_update")
+                       if args.workload == "dense_qp_n4096_m1024" and fused_ok else None)
+            alg_bytes = (pp["fused_bytes"] / pp["fused_launches"]) if fused_ok else None
             roof = dict(
-                bound="mfma", kernel="k_update_jobs (= update role of k_chain_update)",
+                bound="mfma",
+                kernel=("k_chain_update (production launch: the diagonal chain D(k+1) of one "
+                        "workgroup beside the trailing-update tiles of the lazy plan)"
+                        if fused_ok else unfused["kernel"]),
                 achieved=achieved,
                 peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP64_MFMA_TFLOPS,
                 traffic=traffic,
                 algorithmic_bytes_per_launch=alg_bytes,
-                traffic_over_algorithmic=(traffic / alg_bytes) if traffic else None,
-                launches_per_step=pr["update_launches"] / args.steps,
-                avg_launch_us=1e3 * pr["update_ms"] / pr["update_launches"],
-                flops_per_step=pr["update_flops"] / args.steps,
-                factor_ms_per_step=pr["factor_ms"] / args.steps,
-                note=("per-kernel figures from an instrumented pass over the same steps in which "
-                      "the factorisation's kernels run as separate launches with HIP events "
-                      "around them; in the timed region the diagonal chain and the trailing "
-                      "update share one launch (k_chain_update: same tile code, same job "
-                      "table; likewise k_trsm_block and k_update_diag are one launch there, "
-                      "k_trsm_ud); launches follow the lazy plan, so K-depth varies per tile"),
+                traffic_over_algorithmic=(traffic / alg_bytes) if (traffic and alg_bytes) else None,
+                launches_per_step=(pp["fused_launches"] / args.steps) if fused_ok else None,
+                avg_launch_us=(1e3 * pp["fused_ms"] / pp["fused_launches"]) if fused_ok else None,
+                flops_per_step=(pp["fused_flops"] / args.steps) if fused_ok else None,
+                trsm_ud_ms_per_step=pp["trsmud_ms"] / args.steps,
+                first_chain_ms_per_step=pp["chain_ms"] / args.steps,
+                factor_ms_per_step=pp["factor_ms"] / args.steps,
+                unfused_instrumented_schedule=unfused,
+                note=("achieved = algorithmic flops of the launches' update jobs / launch "
+                      "durations (HIP events around every production launch in an instrumented "
+                      "pass over the same steps); a launch lasts as long as the slower of its "
+                      "two roles -- the one-workgroup diagonal chain or the update tiles"),
             )
             # the STEP against the FP64-MFMA roof -- algorithmic flops of one
             # Full Newton step (factor N^3/3, solves 2 N^2, residual 2 n^2 + 4 n m) x steps/s
@@ -438,12 +540,11 @@ def main():
                      "k_trsm_block": pr["trsm_ms"], "k_update_diag": pr["udiag_ms"]}
             dom = max(parts, key=parts.get)
             roof["time_dominant_kernel"] = dict(
-                kernel=dom, ms_per_step=parts[dom] / args.steps,
+                kernel=dom, ms_per_step=parts[dom] / args.steps, schedule="unfused instrumented pass",
                 launches_per_step=(pr["chain_launches"] / args.steps if dom == "k_diag_chain" else None),
                 note=("the factorisation's serial pivot chain: ONE workgroup per 256-column "
                       "block; in the production schedule it runs beside trailing-update tiles "
                       "inside one launch" if dom == "k_diag_chain" else None))
-            roof["kernel_ms_per_step"] = {k: v / args.steps for k, v in parts.items()}
 
     # SURVEY.md 8d "reported separately": the back-solve step of the Simplified policy
     # (2nd+ Newton step of an outer iteration: residual, reduced rhs, forward + backward
@@ -468,12 +569,23 @@ def main():
     # BASELINE configs[3] (what north_star names for multi-GPU scaling): at N > 1 the same
     # launch also times the 256-instance batch, 256 / N instances per rank, one all-gather of
     # 256 residual norms per batched step -- a nested record, strong scaling over N
-    batch_rec = None
-    if world > 1 and args.workload == "dense_qp_n4096_m1024":
+    batch_rec = shard_rec = plugin_rec = None
+    if args.workload == "dense_qp_n4096_m1024" and not (world == 1 and args.no_extras):
         dn.close()
-        batch_rec = bench_batched(args, WORKLOADS["batch256_n1024_m256"], rank, local_rank, world,
-                                  dist, torch, emit=False, steps=min(args.steps, 8), warmup=2)
         dn = None
+        nb_steps = min(args.steps, 8 if world > 1 else 20)
+        batch_rec = bench_batched(args, WORKLOADS["batch256_n1024_m256"], rank, local_rank, world,
+                                  dist, torch, emit=False, steps=nb_steps, warmup=2)
+        if world == 1:
+            # what ONE rank of the 8-GPU run of configs[3] holds: 32 instances on this GPU
+            shard_rec = bench_batched(args, dict(n=1024, m=256, batch=32), rank, local_rank, world,
+                                      dist, torch, emit=False, steps=min(args.steps, 40), warmup=3)
+            if shard_rec is not None and batch_rec is not None:
+                shard_rec["projected_8gpu_scaling_vs_1gpu_batch256"] = dict(
+                    value=8.0 * shard_rec["value"] / batch_rec["value"],
+                    note="PROJECTED: 8 x this rate / the 256-instance rate of one GPU; no "
+                         "multi-GPU run behind it (the all-gather of 256 norms is not in it)")
+            plugin_rec = bench_plugin(problem, x0, y0, local_rank)
     if rank == 0:
         total_steps = args.steps * world
         out = {
@@ -500,6 +612,8 @@ def main():
             "parity": parity,
             "backsolve_step": backsolve,
             "batch256": batch_rec,
+            "shard32": shard_rec,
+            "plugin_step": plugin_rec,
         }
         print(json.dumps(out), flush=True)
     if dn is not None:

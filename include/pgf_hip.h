@@ -197,6 +197,16 @@ int pgf_profile_read(pgf_handle h, double *update_ms, int64_t *update_launches,
 #define PGF_PROF_TRSM_MS 7
 #define PGF_PROF_UDIAG_MS 8
 #define PGF_PROF_COUNT 9
+/* pgf_profile_enable(h, 2): the PRODUCTION launches are timed instead, one HIP-event span per
+ * launch: k_chain_update (the diagonal chain beside the trailing-update tiles; flops / bytes =
+ * the algorithmic work of its update jobs) and k_trsm_ud (T(k) with the next diagonal block's
+ * update); read with count >= PGF_PROF_COUNT2 */
+#define PGF_PROF_FUSED_MS 9
+#define PGF_PROF_FUSED_LAUNCHES 10
+#define PGF_PROF_FUSED_FLOPS 11
+#define PGF_PROF_FUSED_BYTES 12
+#define PGF_PROF_TRSMUD_MS 13
+#define PGF_PROF_COUNT2 14
 int pgf_profile_read_ex(pgf_handle h, double *out, int count);
 
 /* ---- batched mode: many device-resident instances advanced by ONE launch sequence ---- */

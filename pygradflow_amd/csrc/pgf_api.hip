@@ -60,6 +60,9 @@ struct pgf_solver {
   bool lu_active = false;       // the current factor is the LU (until the next factorisation)
   int refine_mode = 1;          // 0 off, 1 check + refine on demand (default)
   double refine_tol = 1e-11, refine_fail = 1e-7;
+  // ||H||_inf, ||J||_inf, ||J||_1 of the matrices in HBM (h_rs[4..6]); computed the first time a
+  // residual misses refine_tol against max |rhs| alone
+  bool norms_valid = false;
   int stat_refined = 0, stat_lu = 0;
   double stat_last_rel = 0.0;
   // the factorisation step's own residual was far below the tolerance: the back-solve steps
@@ -165,18 +168,18 @@ int pgf_create(int n, int m, int device, unsigned flags, pgf_handle *out) {
   A_(q, n) A_(b, m) A_(w, m) A_(tmpn, n) A_(partial, (size_t)PGF_GEMVT_PARTS * (n ? n : 1));
   A_(red, (N + 255) / 256 + 1) A_(scal, 4) A_(meas, 4 * ((N + 255) / 256) + 4);
   if (!sparse) {
-    A_(rs_v, n) A_(rs_lv, n) A_(rs_u, n) A_(rs_wy, m) A_(rs_r, N + 1) A_(rs_d, N + 1) A_(rs_red, 4);
+    A_(rs_v, n) A_(rs_lv, n) A_(rs_u, n) A_(rs_wy, m) A_(rs_r, N + 1) A_(rs_d, N + 1) A_(rs_red, 8);
   }
   A_(mask, n) A_(mask_new, n) A_(idxI, n) A_(idxA, n) A_(pos, n) A_(counts, 4);
 #undef A_
   if ((e = hipHostMalloc((void **)&h->h_counts, 4 * sizeof(int))) != hipSuccess ||
       (e = hipHostMalloc((void **)&h->h_scal, 4 * sizeof(double))) != hipSuccess ||
       (e = hipHostMalloc((void **)&h->h_meas, 4 * sizeof(double))) != hipSuccess ||
-      (e = hipHostMalloc((void **)&h->h_rs, 4 * sizeof(double))) != hipSuccess) {
+      (e = hipHostMalloc((void **)&h->h_rs, 8 * sizeof(double))) != hipSuccess) {
     pgf_destroy(h);
     return PGF_HIP_ERROR + (int)e;
   }
-  for (int i = 0; i < 4; ++i) h->h_rs[i] = 0.0;
+  for (int i = 0; i < 8; ++i) h->h_rs[i] = 0.0;
   h->sparse = sparse;
   if (sparse) {
     // banded mode: no dense N x N storage; only the factor's flag words are shared
@@ -325,6 +328,7 @@ int pgf_set_derivs_dense(pgf_handle h, const double *H, int64_t ldh, const doubl
   if ((rc = set_matrix(h, H, ldh, h->n, h->n, loc, &h->Hown, &h->H, &h->ldh, &h->ownH))) return rc;
   if ((rc = set_matrix(h, J, ldj, h->m, h->n, loc, &h->Jown, &h->J, &h->ldj, &h->ownJ))) return rc;
   h->derivs_set = true;
+  h->norms_valid = false;
   invalidate_factor(h);
   return PGF_OK;
 }
@@ -392,6 +396,7 @@ int pgf_set_derivs_csr(pgf_handle h, const int *Hptr, const int *Hidx, const dou
                                 &h->ownJ)))
     return rc;
   h->derivs_set = true;
+  h->norms_valid = false;
   invalidate_factor(h);
   return PGF_OK;
 }
@@ -565,10 +570,32 @@ static void enqueue_residual(pgf_handle h, bool may_skip = false) {
   (void)hipMemcpyAsync(h->h_rs, h->rs_red, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
 }
 
+// The measure of a solve: max |rhs - K s| against max |rhs| -- and, once the matrices' norms are
+// known (residual_norms), against ||K|| max |s| + max |rhs|: the normwise backward error.  A
+// backward-stable solve only guarantees |r| <~ eps ||K|| ||s||, which is eps cond(K) ||rhs||: at
+// cond(K) ~ 1e5 and beyond the first form alone would send good solves into refinement, and at
+// ~1e9 not even the pivoted LU could meet it -- the reference's splu accepts those solves
+// (lu_solver.py:14-21).  ||K||_inf <= max(||H||_inf + lambda + ||J||_1, ||J||_inf + delta): the
+// reduced matrix is a principal submatrix of that one.
 static double residual_rel(pgf_handle h) {
-  const double r = h->h_rs[0], b = h->h_rs[1];
+  const double r = h->h_rs[0], b = h->h_rs[1], sn = h->h_rs[2];
   if (!(r == r) || !(r <= 1.79e308)) return HUGE_VAL;
-  return r / (b > 0.0 ? b : 1.0);
+  double den = b;
+  if (h->norms_valid) {
+    const double nK = std::max(h->h_rs[4] + h->lamb + h->h_rs[6], h->h_rs[5] + h->delta);
+    if (sn == sn && sn <= 1.79e308) den += nK * sn;
+  }
+  return r / (den > 0.0 ? den : 1.0);
+}
+// the norms of H and J in HBM (one pass over both, one synchronisation; cached until the next
+// pgf_set_derivs_*)
+static int residual_norms(pgf_handle h) {
+  if (h->norms_valid) return PGF_OK;
+  launch_matrix_norms(h->stream, h->n, h->m, h->H, h->ldh, h->J, h->ldj, h->rs_red + 4);
+  HIPCHK(h, hipMemcpyAsync(h->h_rs + 4, h->rs_red + 4, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->norms_valid = true;
+  return PGF_OK;
 }
 
 // After a host synchronisation (and chain_recover): the unpivoted LDL^T is backward stable only
@@ -586,6 +613,12 @@ static int refine_if_needed(pgf_handle h, bool swapped, bool with_step = true) {
   if (h->sparse) return sparse_refine(h, swapped, with_step);
   if (!h->refine_mode || h->N == 0 || h->rs_skipped) return PGF_OK;
   double rel = residual_rel(h);
+  int rc;
+  if (rel > h->refine_tol && !h->norms_valid) {
+    // missed against max |rhs| alone: take the size of K and of the solution into account
+    if ((rc = residual_norms(h))) return rc;
+    rel = residual_rel(h);
+  }
   h->stat_last_rel = rel;
   if (h->last_solve == 1) h->factor_clean = rel <= 1e-3 * h->refine_tol;
   if (rel <= h->refine_tol) return PGF_OK;
@@ -608,7 +641,6 @@ static int refine_if_needed(pgf_handle h, bool swapped, bool with_step = true) {
     if (ldlt_chain_check(h->fac)) return fail(h, PGF_HIP_ERROR, k_chain_msg);
     return PGF_OK;
   };
-  int rc;
   for (int it = 0; it < 2 && rel > h->refine_tol && rel < 1.0 && !h->lu_active; ++it) {
     HIPCHK(h, ldlt_solve_async(h->fac, h->rs_r, h->rs_d));
     launch_axpy1(s, h->N, h->rs_d, h->sol);
@@ -1981,6 +2013,7 @@ int pgf_stream(pgf_handle h, void **stream_out) {
 int pgf_profile_enable(pgf_handle h, int on) {
   if (!h) return PGF_INVALID;
   h->prof.enabled = on != 0;
+  h->prof.mode = on == 2 ? 2 : 1;
   return PGF_OK;
 }
 
@@ -2008,6 +2041,20 @@ static void profile_collect(PgfProfile &p) {
     }
     v.clear();
   };
+  for (size_t i = 0; i < p.fused_spans.size(); ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.fused_spans[i].first, p.fused_spans[i].second) == hipSuccess)
+      p.acc_fused_ms += ms;
+    p.acc_fused_flops += p.fused_flops[i];
+    p.acc_fused_bytes += p.fused_bytes[i];
+    p.acc_fused_launches += 1;
+    p.pool.push_back(p.fused_spans[i].first);
+    p.pool.push_back(p.fused_spans[i].second);
+  }
+  p.fused_spans.clear();
+  p.fused_flops.clear();
+  p.fused_bytes.clear();
+  drain(p.trsmud_spans, p.acc_trsmud_ms, nullptr);
   drain(p.factor_spans, p.acc_factor_ms, nullptr);
   drain(p.chain_spans, p.acc_chain_ms, &p.acc_chain_launches);
   drain(p.trsm_spans, p.acc_trsm_ms, nullptr);
@@ -2018,6 +2065,8 @@ static void profile_reset(PgfProfile &p) {
   p.acc_update_ms = p.acc_update_flops = p.acc_update_bytes = p.acc_factor_ms = 0;
   p.acc_chain_ms = p.acc_trsm_ms = p.acc_udiag_ms = 0;
   p.acc_update_launches = p.acc_chain_launches = 0;
+  p.acc_fused_ms = p.acc_fused_flops = p.acc_fused_bytes = p.acc_trsmud_ms = 0;
+  p.acc_fused_launches = 0;
 }
 
 int pgf_profile_read(pgf_handle h, double *update_ms, int64_t *update_launches,
@@ -2050,6 +2099,13 @@ int pgf_profile_read_ex(pgf_handle h, double *out, int count) {
   out[PGF_PROF_CHAIN_LAUNCHES] = (double)p.acc_chain_launches;
   out[PGF_PROF_TRSM_MS] = p.acc_trsm_ms;
   out[PGF_PROF_UDIAG_MS] = p.acc_udiag_ms;
+  if (count >= PGF_PROF_COUNT2) {
+    out[PGF_PROF_FUSED_MS] = p.acc_fused_ms;
+    out[PGF_PROF_FUSED_LAUNCHES] = (double)p.acc_fused_launches;
+    out[PGF_PROF_FUSED_FLOPS] = p.acc_fused_flops;
+    out[PGF_PROF_FUSED_BYTES] = p.acc_fused_bytes;
+    out[PGF_PROF_TRSMUD_MS] = p.acc_trsmud_ms;
+  }
   profile_reset(p);
   return PGF_OK;
 }

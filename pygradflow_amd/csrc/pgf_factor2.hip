@@ -1782,7 +1782,8 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
   };
   // T(c0) -- with the update of the next diagonal block in the same launch (k_trsm_ud) unless
   // per-kernel events are wanted or there is no next block
-  const bool fud = fused_ud() && !p;
+  const bool prod = p && p->mode == 2;  // production launches, one span each
+  const bool fud = fused_ud() && (!p || prod);
   auto launch_t = [&](int c0, double *Wb) {
     const int nb = std::min(OB, N - c0);
     const int below = nrows - (c0 + nb);
@@ -1794,8 +1795,10 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
       const int rest = nT - nA;  // row groups at the ordinary ids
       const int last = rest > 0 ? (rest - 1 < 7 * S ? (rest - 1) + (rest - 1) / 7 + 1 : rest - 1 + S) : 0;
       const int grid = std::max(8 * (S - 1) + 1, last + 1);
+      if (prod) span_begin(pr.trsmud_spans);
       hipLaunchKernelGGL(k_trsm_ud, dim3(grid), dim3(256), 0, s, f.K, f.ldk, Wb, ldw, nrows, c0, nb,
                          f.dinv, f.Linv, N, f.hctl, next_help_epoch(), f.flags);
+      if (prod) span_end(pr.trsmud_spans);
       return;
     }
     span_begin(pr.trsm_spans);
@@ -1805,7 +1808,7 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
   };
   // Lazy trailing update (production; plan_updates above).  PGF_LAZY_BUDGET fixes the budget
   // (0 = no limit = the eager schedule: every launch applies its block everywhere).
-  const bool lazy = fused() && !p;  // one launch for chain + update; else two, same jobs
+  const bool lazy = fused() && (!p || prod);  // one launch for chain + update; else two, same jobs
   const int nblk = (N + OB - 1) / OB;
   UpdPlan plan;
   if (nblk > 1) {
@@ -1847,6 +1850,20 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
     }
     plan = cplan;
   }
+  // algorithmic work of a launch's update jobs: entries (i, j), j <= i, of every job's region, 2 KB
+  // flops each; bytes: every such entry read and written once, the L rows of the region's rows
+  // and of its columns once per job
+  auto job_work = [&](const UpdJobs &js, double &fl, double &by) {
+    fl = by = 0.0;
+    for (int q = 0; q < js.njobs; ++q) {
+      const int col0 = js.col0[q], colEnd = std::min(N, col0 + 128 * js.ntc[q]);
+      const int rs = std::max(js.rowstart[q], col0);
+      double cnt = 0.0;
+      for (int i = rs; i < nrows; ++i) cnt += std::min(colEnd, i + 1) - col0;
+      fl += 2.0 * cnt * js.KB[q];
+      by += 16.0 * cnt + 8.0 * js.KB[q] * ((double)(nrows - rs) + (double)(colEnd - col0));
+    }
+  };
   int buf = 0;
   if (N > 0) {
     launch_d(0);
@@ -1868,6 +1885,13 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
       const UpdJobs &js = plan.launch[c0 / OB];
       const int ntiles = js.tile_begin[js.njobs];
       const int ep = next_help_epoch();
+      if (prod) {
+        span_begin(pr.fused_spans);
+        double fl, by;
+        job_work(js, fl, by);
+        p->fused_flops.push_back(fl);
+        p->fused_bytes.push_back(by);
+      }
       if (chain3_on())
         hipLaunchKernelGGL(k_chain3_update, dim3(1 + ntiles), dim3(1024), 0, s, f.K, f.ldk, c1, nb1,
                            f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, N, nrows, js);
@@ -1879,6 +1903,7 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
         hipLaunchKernelGGL(k_chain_update<false>, dim3(1 + ntiles), dim3(1024), 0, s, f.K, f.ldk,
                            c1, nb1, f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, f.hctl, ep, N, nrows,
                            js);
+      if (prod) span_end(pr.fused_spans);
     } else {
       launch_d(c1);
       const UpdJobs &js = plan.launch[c0 / OB];
@@ -1895,18 +1920,8 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
         if (p) {
           (void)hipEventRecord(e1, s);
           p->update_spans.emplace_back(e0, e1);
-          // algorithmic work of the launch: entries (i, j), j <= i, of every job's region, 2 KB
-          // flops each; bytes: every such entry read and written once, the L rows of the
-          // region's rows and of its columns once per job
-          double fl = 0.0, by = 0.0;
-          for (int q = 0; q < js.njobs; ++q) {
-            const int col0 = js.col0[q], colEnd = std::min(N, col0 + 128 * js.ntc[q]);
-            const int rs = std::max(js.rowstart[q], col0);
-            double cnt = 0.0;
-            for (int i = rs; i < nrows; ++i) cnt += std::min(colEnd, i + 1) - col0;
-            fl += 2.0 * cnt * js.KB[q];
-            by += 16.0 * cnt + 8.0 * js.KB[q] * ((double)(nrows - rs) + (double)(colEnd - col0));
-          }
+          double fl, by;
+          job_work(js, fl, by);
           p->update_flops.push_back(fl);
           p->update_bytes.push_back(by);
         }

@@ -12,6 +12,14 @@
 
 struct PgfProfile {
   bool enabled = false;
+  // 1: the factorisation's kernels as separate launches, one span each (per-kernel figures);
+  // 2: the PRODUCTION launches (diagonal chain beside the trailing update, T(k) with the next
+  //    diagonal block's update), one span per launch
+  int mode = 1;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> fused_spans, trsmud_spans;
+  std::vector<double> fused_flops, fused_bytes;
+  double acc_fused_ms = 0, acc_fused_flops = 0, acc_fused_bytes = 0, acc_trsmud_ms = 0;
+  int64_t acc_fused_launches = 0;
   std::vector<hipEvent_t> pool;  // recycled event pairs
   std::vector<std::pair<hipEvent_t, hipEvent_t>> update_spans;
   std::vector<double> update_flops;

@@ -55,3 +55,6 @@ void launch_kkt_residual(hipStream_t s, int n, int m, int nI, double lamb, doubl
                          double *partial, int nparts, double *r, double *red3);
 void launch_axpy1(hipStream_t s, int N, const double *d, double *x);
 void launch_symmetrize(hipStream_t s, double *A, int64_t ld, int N);
+// ||H||_inf, ||J||_inf, ||J||_1 -> norms3 (device), for the normwise backward error of the guard
+void launch_matrix_norms(hipStream_t s, int n, int m, const double *H, int64_t ldh, const double *J,
+                         int64_t ldj, double *norms3);

@@ -794,6 +794,47 @@ void launch_kkt_residual(hipStream_t s, int n, int m, int nI, double lamb, doubl
                      reinterpret_cast<unsigned long long *>(red3));
 }
 
+// ---- matrix norms for the normwise backward error of the residual guard (pgf_api.hip)
+// out[0] = max_i sum_j |A_ij| (rows x cols, row-major): one workgroup per row; non-negative
+// doubles order like their bit patterns, so atomicMax on the 64-bit words does the reduction
+__global__ __launch_bounds__(256) void k_abs_rowsum_max(int cols, const double *__restrict__ A, int64_t ld,
+                                                        unsigned long long *__restrict__ out) {
+  __shared__ double part[4];
+  const double *row = A + (int64_t)blockIdx.x * ld;
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < cols; j += 256) acc += fabs(row[j]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = part[0] + part[1] + part[2] + part[3];
+    if (t == t) atomicMax(out, (unsigned long long)__double_as_longlong(t));
+  }
+}
+// out[0] = max_j sum_i |A_ij|: one thread per column (coalesced across the threads of a row)
+__global__ __launch_bounds__(256) void k_abs_colsum_max(int rows, int cols, const double *__restrict__ A,
+                                                        int64_t ld, unsigned long long *__restrict__ out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  double acc = 0.0;
+  if (j < cols)
+    for (int i = 0; i < rows; ++i) acc += fabs(A[(int64_t)i * ld + j]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc = fmax(acc, __shfl_down(acc, off));
+  if ((threadIdx.x & 63) == 0 && acc == acc) atomicMax(out, (unsigned long long)__double_as_longlong(acc));
+}
+// norms3: ||H||_inf, ||J||_inf, ||J||_1 (zeroed here)
+void launch_matrix_norms(hipStream_t s, int n, int m, const double *H, int64_t ldh, const double *J,
+                         int64_t ldj, double *norms3) {
+  (void)hipMemsetAsync(norms3, 0, 3 * sizeof(double), s);
+  unsigned long long *o = reinterpret_cast<unsigned long long *>(norms3);
+  if (n && H) hipLaunchKernelGGL(k_abs_rowsum_max, dim3(n), dim3(256), 0, s, n, H, ldh, o);
+  if (n && m && J) {
+    hipLaunchKernelGGL(k_abs_rowsum_max, dim3(m), dim3(256), 0, s, n, J, ldj, o + 1);
+    hipLaunchKernelGGL(k_abs_colsum_max, g1(n), dim3(256), 0, s, m, n, J, ldj, o + 2);
+  }
+}
+
 void launch_axpy1(hipStream_t s, int N, const double *d, double *x) {
   if (N) hipLaunchKernelGGL(k_axpy1, g1(N), dim3(256), 0, s, N, d, x);
 }

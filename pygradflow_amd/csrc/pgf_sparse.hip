@@ -907,7 +907,7 @@ __global__ void k_bcr_scatter(const double *__restrict__ X, double *__restrict__
 
 // Accuracy guard of the banded path: r = rhs0 - K x with K read from the assembled band (cyclic
 // reduction leaves it intact; lower band, row i holds K[i][i - d] at [i][d]), max |r| and
-// max |rhs0| per workgroup.
+// max (|K| |x| + |rhs0|) per workgroup.
 __global__ __launch_bounds__(256) void k_band_residual(const double *__restrict__ band, int ldb, int bw,
                                                        int N, const double *__restrict__ x,
                                                        const double *__restrict__ rhs0,
@@ -932,12 +932,21 @@ __global__ __launch_bounds__(256) void k_band_residual(const double *__restrict_
   }
   __syncthreads();
   const int i = i0 + tid;
+  // ab: the row's share of the normwise backward error's denominator, (|K| |x| + |rhs|)_i <=
+  // ||K|| max |x| + max |rhs| -- a backward-stable solve only guarantees |r| <~ eps |K| |x|, which
+  // against max |rhs| alone is eps cond(K) (pgf_api.hip, residual_rel)
   double ar = 0.0, ab = 0.0;
   if (i < N) {
     double acc = rhs0[i];
     ab = fabs(acc);
-    for (int d = 0; d <= bw && d <= i; ++d) acc = fma(-bs[tid * ldb + d], xs[bw + tid - d], acc);
-    for (int d = 1; d <= bw && i + d < N; ++d) acc = fma(-bs[(tid + d) * ldb + d], xs[bw + tid + d], acc);
+    for (int d = 0; d <= bw && d <= i; ++d) {
+      acc = fma(-bs[tid * ldb + d], xs[bw + tid - d], acc);
+      ab += fabs(bs[tid * ldb + d] * xs[bw + tid - d]);
+    }
+    for (int d = 1; d <= bw && i + d < N; ++d) {
+      acc = fma(-bs[(tid + d) * ldb + d], xs[bw + tid + d], acc);
+      ab += fabs(bs[(tid + d) * ldb + d] * xs[bw + tid + d]);
+    }
     r[i] = acc;
     ar = (acc == acc) ? fabs(acc) : __builtin_huge_val();
   }

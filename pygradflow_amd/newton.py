@@ -309,16 +309,20 @@ class DeviceNewton:
         return dict(stat_res=out[0], cons_violation=out[1], bound_violation=out[2], y_inf=out[3])
 
     def profile(self, on=True):
+        """on = True / 1: the factorisation's kernels as separate launches with a HIP-event span
+        each (per-kernel figures); 2: spans around the PRODUCTION launches (``fused_*``:
+        k_chain_update, ``trsmud_ms``: k_trsm_ud); False: off."""
         _lib.check(self._lib.pgf_profile_enable(self._hd.h, int(on)), self._hd.h)
 
     def profile_read(self):
-        out = np.zeros(9)
+        out = np.zeros(14)
         _lib.check(self._lib.pgf_profile_read_ex(self._hd.h, _lib.dptr(out), out.size), self._hd.h)
         keys = ("update_ms", "update_launches", "update_flops", "update_bytes", "factor_ms",
-                "chain_ms", "chain_launches", "trsm_ms", "udiag_ms")
+                "chain_ms", "chain_launches", "trsm_ms", "udiag_ms", "fused_ms", "fused_launches",
+                "fused_flops", "fused_bytes", "trsmud_ms")
         rec = dict(zip(keys, (float(v) for v in out)))
-        rec["update_launches"] = int(rec["update_launches"])
-        rec["chain_launches"] = int(rec["chain_launches"])
+        for k in ("update_launches", "chain_launches", "fused_launches"):
+            rec[k] = int(rec[k])
         return rec
 
     def close(self):

@@ -65,12 +65,37 @@ class LinearQuadraticProblem(_ProblemShape):
         super().__init__(lb, ub, m)
         assert Q.shape == (n, n)
         assert A.shape == (m, n)
+        self._pgf_version = 0
         self.Q = Q
         self.q = np.asarray(q, dtype=np.float64)
         self.A = A
         self.b = np.asarray(b, dtype=np.float64)
-        self._Qs = None
-        self._As = None
+
+    # Q, A, q, b stay resident in HBM across Newton and outer steps (``pgf_constant_derivs``),
+    # keyed on (problem object, version): ASSIGNING a new array bumps the version and the data are
+    # uploaded again; the arrays themselves are frozen (``writeable = False``), so that an
+    # in-place edit -- which no key could notice short of hashing 168 MB per step -- raises
+    # instead of silently leaving a stale copy on the device.
+    @staticmethod
+    def _freeze(arr):
+        if sps.issparse(arr):
+            for part in ("data", "indices", "indptr"):
+                a = getattr(arr, part, None)
+                if isinstance(a, np.ndarray):
+                    a.flags.writeable = False
+        elif isinstance(arr, np.ndarray):
+            arr.flags.writeable = False
+        return arr
+
+    def _set(self, name, value):
+        setattr(self, "_" + name, self._freeze(value))
+        self._pgf_version += 1
+        self._Qs = self._As = None
+
+    Q = property(lambda self: self._Q, lambda self, v: self._set("Q", v))
+    A = property(lambda self: self._A, lambda self, v: self._set("A", v))
+    q = property(lambda self: self._q, lambda self, v: self._set("q", np.asarray(v, dtype=np.float64)))
+    b = property(lambda self: self._b, lambda self, v: self._set("b", np.asarray(v, dtype=np.float64)))
 
     # dense / sparse agnostic helpers -------------------------------------
     @property

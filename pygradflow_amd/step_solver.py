@@ -72,26 +72,37 @@ class _Handle:
 POOL = _HandlePool()
 
 
-def _sample_sum(arr):
-    """Cheap content fingerprint of an array (at most ~4096 strided entries)."""
+def _content_hash(arr):
+    """Hash of an array's FULL content (xxh3 where available: ~10 GB/s; else blake2b)."""
     if arr is None:
-        return 0.0
-    if sps.issparse(arr):
-        arr = arr.data
-    flat = np.asarray(arr).ravel()
-    if flat.size == 0:
-        return 0.0
-    step = max(1, flat.size // 4096)
-    return float(flat[::step].sum()) + float(flat[-1])
+        return 0
+    parts = [arr.data, arr.indices, arr.indptr] if sps.issparse(arr) else [arr]
+    try:
+        import xxhash
+
+        hs = xxhash.xxh3_64()
+    except Exception:  # pragma: no cover
+        import hashlib
+
+        hs = hashlib.blake2b(digest_size=8)
+    for part in parts:
+        a = np.ascontiguousarray(part)
+        hs.update(str(a.shape).encode())
+        hs.update(memoryview(a).cast("B"))
+    return hs.intdigest() if hasattr(hs, "intdigest") else int.from_bytes(hs.digest(), "little")
 
 
 def residency_key(problem):
     """Identity under which a constant-derivative problem's H, J (and q, b) stay resident in
-    HBM: a token pinned to the problem object (so that an id cannot be recycled) PLUS a content
-    fingerprint of its arrays -- a problem whose Q / A / q / b are modified in place keeps its
-    token but not its fingerprint, and is uploaded again instead of silently reusing the stale
-    matrices.  Invalidation rule: replace the arrays, or change their entries; both
-    are noticed unless a change cancels exactly in the strided sample sums."""
+    HBM: a token pinned to the problem object (so that an id cannot be recycled) PLUS the
+    state of its data --
+      * ``LinearQuadraticProblem``: a version counter that every assignment to Q / A / q / b
+        bumps; the arrays themselves are frozen, an in-place edit raises (problems.py), so the
+        counter cannot miss a change;
+      * any other problem that declares ``pgf_constant_derivs``: a hash of the FULL content of
+        its Q / A / q / b (a strided sample, as in round 2, misses edits between the samples:
+        ADVICE r2).
+    A stale key means: upload again."""
     token = getattr(problem, "_pgf_token", None)
     if token is None:
         token = object()
@@ -99,7 +110,10 @@ def residency_key(problem):
             problem._pgf_token = token
         except Exception:
             return None
-    fp = tuple(_sample_sum(getattr(problem, nm, None)) for nm in ("Q", "A", "q", "b"))
+    version = getattr(problem, "_pgf_version", None)
+    if version is not None:
+        return (token, ("v", int(version)))
+    fp = tuple(_content_hash(getattr(problem, nm, None)) for nm in ("Q", "A", "q", "b"))
     return (token, fp)
 
 

@@ -63,6 +63,26 @@ def test_oracle_policies_step_for_step(name):
             assert G.rel_err(rec["yn"], case[pre + "yn"]) <= 1e-12, (pol, k)
 
 
+@pytest.mark.parametrize("name", G.illcond_case_names())
+def test_oracle_illconditioned_cases(name):
+    """cond(K) 2e7 ... 4e9 (illcond_*.npz): the restatement makes the reference's own bmat + splu
+    calls, so it reproduces the reference's solution far inside the reference's own forward
+    error (stored per step against an extended-precision solve), masks bit for bit."""
+    case = G.load_case(name)
+    problem = G.rebuild_problem(case)
+    dt, rho = float(case["dt"]), float(case["rho"])
+    orc = O.NewtonOracle(problem, "Full", case["x0"], case["y0"], dt, rho, None)
+    recs = orc.run(case["x0"], case["y0"], int(case["steps"]))
+    for k, rec in enumerate(recs):
+        pre = f"Full/{k}/"
+        assert float(case[pre + "cond"]) > 1e7
+        tol = max(1e-12, 0.1 * float(case[pre + "ref_err"]))
+        assert np.array_equal(rec["mask"], case[pre + "mask"]), k
+        assert G.rel_err(rec["s"], case[pre + "s"]) <= tol, k
+        assert G.rel_err(rec["xn"], case[pre + "xn"]) <= tol, k
+        assert G.rel_err(rec["yn"], case[pre + "yn"]) <= tol, k
+
+
 def test_oracle_linear_solver_vectors():
     import scipy.sparse as sps
 
