@@ -158,11 +158,16 @@ def bench_batched(args, wl, rank, local_rank, world, dist, torch, emit=True, ste
     for i in range(nwarm):
         one_step(i)
     fence()
+    # (the instance generators leave garbage behind: a cyclic collection inside the timed loop
+    # stalls ONE batched step by tens of milliseconds)
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for i in range(nsteps):
         norms = one_step(i)
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
