@@ -1490,7 +1490,7 @@ int pgf_batch_create(const pgf_handle *handles, int count, pgf_batch *out) {
   if ((e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipMalloc((void **)&b->tab, count * sizeof(BInst))) != hipSuccess ||
       (e = hipMalloc((void **)&b->ctl, (size_t)count * 4 * sizeof(int))) != hipSuccess ||
-      (e = hipMalloc((void **)&b->flags_out, (size_t)count * 3 * sizeof(int))) != hipSuccess ||
+      (e = hipMalloc((void **)&b->flags_out, ((size_t)count * 3 + 1) * sizeof(int))) != hipSuccess ||
       (e = hipMalloc((void **)&b->diff_out, count * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void **)&b->norm_out, count * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void **)&b->red4,
@@ -1571,7 +1571,7 @@ int pgf_batch_create(const pgf_handle *handles, int count, pgf_batch *out) {
   if ((e = hipMemcpy(b->tab, tab.data(), count * sizeof(BInst), hipMemcpyHostToDevice)) !=
           hipSuccess ||
       (e = hipMemset(b->ctl, 0, (size_t)count * 4 * sizeof(int))) != hipSuccess ||
-      (e = hipMemset(b->flags_out, 0, (size_t)count * 3 * sizeof(int))) != hipSuccess) {
+      (e = hipMemset(b->flags_out, 0, ((size_t)count * 3 + 1) * sizeof(int))) != hipSuccess) {
     pgf_batch_destroy(b);
     return PGF_HIP_ERROR + (int)e;
   }
@@ -1825,6 +1825,25 @@ int pgf_batch_ctl_read(pgf_batch b, double *lamb, uint8_t *accepted, double *log
   if (!b->dctl_cs) return bfail(b, PGF_NOT_READY, "pgf_batch_ctl_init first");
   (void)hipSetDevice(b->device);
   BHIPCHK(b, hipStreamSynchronize(b->stream));
+  // A failed hand-over of a chain helper or of a chained solve looked like a singular matrix to
+  // the device-resident controller (kb_dctl_mid / _end: reject, 2 lambda) -- correct for that
+  // iteration, but with the helpers still on it could repeat every iteration and lambda would
+  // grow without bound.  The sticky word behind the flag triples says whether any
+  // step of the loop saw one: helpers and chained solves go off, as pgf_batch_sync does.
+  {
+    int sticky = 0;
+    BHIPCHK(b, hipMemcpy(&sticky, b->flags_out + 3 * (size_t)b->B, sizeof(int), hipMemcpyDeviceToHost));
+    if (sticky) {
+      ldlt_chain_helpers_off();
+      ldlt_chain_set_enabled(false);
+      for (int i = 0; i < b->B; ++i) {
+        DenseLdlt &f = b->hs[i]->fac;
+        BHIPCHK(b, hipMemsetAsync(f.xpub, 0xff, 2 * (size_t)f.chain_stride * 64 * sizeof(double), b->stream));
+      }
+      BHIPCHK(b, hipMemsetAsync(b->flags_out + 3 * (size_t)b->B, 0, sizeof(int), b->stream));
+      BHIPCHK(b, hipStreamSynchronize(b->stream));
+    }
+  }
   std::vector<double> cs((size_t)b->B * DCS_STRIDE);
   BHIPCHK(b, hipMemcpy(cs.data(), b->dctl_cs, cs.size() * sizeof(double), hipMemcpyDeviceToHost));
   for (int i = 0; i < b->B; ++i) {
@@ -1863,6 +1882,7 @@ int pgf_batch_sync(pgf_batch b, int *status, int *n_neg, double *diff) {
     if (b->h_flags[3 * i] & 2) {
       // (or one of its chained solves: those go off too, and the publication halves of the
       // instance's handle get their sentinels back)
+      (void)hipMemsetAsync(b->flags_out + 3 * (size_t)b->B, 0, sizeof(int), b->stream);
       ldlt_chain_helpers_off();
       ldlt_chain_set_enabled(false);
       DenseLdlt &f = b->hs[i]->fac;

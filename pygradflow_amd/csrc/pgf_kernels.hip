@@ -1071,6 +1071,9 @@ __global__ __launch_bounds__(256) void kb_step_final(const BInst *__restrict__ t
     // bit 2: the sampled residual of the solve is too large (kb_sample_residual)
     const int bad = (I.flags[0] ? 1 : 0) | ((I.flags[2] || I.cctl[1]) ? 2 : 0) | (I.flags[3] ? 4 : 0);
     I.cctl[1] = 0;
+    // (sticky, behind the per-instance triples: a device-resident controller loop overwrites the
+    // triples step after step; pgf_batch_ctl_read must still learn that a hand-over failed)
+    if (bad & 2) atomicOr(flags_out + 3 * gridDim.z, 1);
     flags_out[3 * blockIdx.z] = bad;
     flags_out[3 * blockIdx.z + 1] = I.flags[1];
     flags_out[3 * blockIdx.z + 2] = I.counts[0];

@@ -281,3 +281,37 @@ def test_device_resident_controller_against_reference_trajectory(pgf, newton_typ
     x, y = bd.points()
     assert G.rel_err(x[0], case["x"][-1]) <= 1e-9 and G.rel_err(y[0], case["y"][-1]) <= 1e-9
     bd.close()
+
+
+@pytest.mark.gpu
+def test_device_resident_controller_notices_a_failed_helper_handover(pgf):
+    """inside pgf_batch_ctl_iterate a failed chain-helper hand-over looks like a
+    singular matrix to the device-resident controller (reject, 2 lambda) and its flag is
+    overwritten by the next step; pgf_batch_ctl_read must still learn of it (sticky word) and
+    switch the helpers off, so that the failure cannot repeat iteration after iteration.  The
+    run then continues to the same accept / reject pattern as an undisturbed batch from the
+    iteration after the injected failure on."""
+    from pygradflow_amd import _lib, problems
+    from pygradflow_amd.batched import BatchedDeviceNewton
+
+    lib = _lib.load()
+    B, n, m = 3, 400, 100
+    make = lambda i: problems.dense_qp(n, m, seed=60 + i, boxed_frac=0.1, box=0.05)
+    par = Params(newton_type="Full", lamb_init=1.0)
+    lib.pgf_debug_chain_helpers(1)
+    bd = BatchedDeviceNewton(make, B, "Full", 1.0, 1.0)
+    try:
+        ctl = SC.DeviceResidentDistanceRatioController(bd, par, rho=1.0, max_iterations=6)
+        _lib.check(lib.pgf_batch_debug_fail_next_helper(bd._b))
+        ctl.run(2)
+        # instance 0's first iteration was rejected (its factorisation reported failed helpers)
+        assert ctl.history[0, 0, 2] == 0.0
+        assert ctl.history[0, 1:, 2].all()
+        assert lib.pgf_debug_chain_helpers(-1) == 0  # switched off by pgf_batch_ctl_read
+        ctl.run(3)
+        assert ctl.history[2:5, :, 2].all()  # no further failures: lambda does not run away
+        assert np.all(ctl.lamb < 10.0)
+    finally:
+        lib.pgf_debug_chain_helpers(1)
+        lib.pgf_debug_chain_enable(1)
+        bd.close()
