@@ -337,6 +337,184 @@ __global__ __launch_bounds__(256) void kb_trsm_block(const BInst *__restrict__ t
 }
 
 // ------------------------------------------------------------------ D(k)
+#ifndef PGF_CHAIN_DPP
+#define PGF_CHAIN_DPP 1  // 0: the v_readlane / LDS-broadcast elimination of round 2 (below)
+#endif
+#if PGF_CHAIN_DPP
+// Round 3: the elimination with DPP row broadcasts.  gfx950 has 64-bit DPP operands for
+// row_newbcast ("DP ALU DPP"): v_fmac_f64_dpp acc, src row_newbcast:k, mult adds (lane k's src of
+// the own row of 16 lanes) * mult -- ONE instruction per entry of a rank-1 update instead of two
+// v_readlane + FMA, issued every 4 cycles (tools/chain_dpp_test.hip: a 16 x 16 tile in 0.83 us
+// against 1.45, with 64 rows riding along 1.06 against 1.65).  Every row of 16 lanes therefore
+// holds the whole pivot tile (lane r <-> pivot row r, all four rows of lanes the same), and each
+// lane one more row that rides along: its row of the 64 x 64 diagonal tile (chain_a_plus) or of
+// the rows below (chain_b_own).
+template <int L>
+__device__ __forceinline__ double dpp_bcast(double v) {
+  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + L, 0xf, 0xf, false);
+}
+// acc += (lane L's src) * mult.  FRESH: two wait states first -- a DPP operand written by the
+// instruction right before is read stale otherwise (inline assembly is invisible to the
+// compiler's hazard recogniser).
+template <int L, bool FRESH = false>
+__device__ __forceinline__ void dpp_fmac(double &acc, double src, double mult) {
+  if (FRESH)
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc)
+                 : "v"(src), "v"(mult), "n"(L));
+  else
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc)
+                 : "v"(src), "v"(mult), "n"(L));
+}
+
+// column C of chain_a_plus: a[] = the lane's pivot row (entries <= row valid), b[] = its riding
+// row; r = 1 / a[C] of the own lane (meaningful in lane C), npc = -a[C] * a[C + 1][C].  The
+// riding row's L entry and W entry of column C go to LDS at once (mrow / wrow: byte addresses of
+// M[row][cb] and Wt[row][0]): the stores drain beside the arithmetic.
+template <int C>
+__device__ __forceinline__ void chain_a_col(double (&a)[16], double (&b)[16], double &r, double &npc,
+                                            double &dmine, int prow, double *mrow, double *wrow) {
+  constexpr int C1 = (C + 1) & 15, C2 = (C + 2) & 15;
+  double rn = 0.0, npn = 0.0;
+  if (C + 1 < 16) {
+    // the pivot chain: next pivot's column first, its reciprocal in flight behind the rest
+    dpp_fmac<C, true>(a[C1], r, npc);
+    rn = __builtin_amdgcn_rcp(a[C1]);
+  }
+  const double rb = dpp_bcast<C>(r);
+  const double l = -a[C] * rb;   // -L[pivot row][C] (junk on and above the diagonal: never used)
+  const double mr = -b[C] * rb;  // -L[riding row][C]
+  if (C + 2 < 16) npn = -a[C1] * dpp_bcast<C2>(a[C1]);
+  mrow[C] = -mr;
+  wrow[C] = b[C];
+#define CH_UA(K) \
+  if (K > C + 1) dpp_fmac<K>(a[K], a[C], l);
+  CH_UA(2) CH_UA(3) CH_UA(4) CH_UA(5) CH_UA(6) CH_UA(7) CH_UA(8) CH_UA(9) CH_UA(10) CH_UA(11)
+  CH_UA(12) CH_UA(13) CH_UA(14) CH_UA(15)
+#undef CH_UA
+#define CH_UB(K) \
+  if (K > C) dpp_fmac<K>(b[K], a[C], mr);
+  CH_UB(1) CH_UB(2) CH_UB(3) CH_UB(4) CH_UB(5) CH_UB(6) CH_UB(7) CH_UB(8) CH_UB(9) CH_UB(10)
+  CH_UB(11) CH_UB(12) CH_UB(13) CH_UB(14) CH_UB(15)
+#undef CH_UB
+  dmine = (prow == C) ? a[C] : dmine;
+  if (C + 1 < 16) {
+    rn = fma(rn, fma(-a[C1], rn, 1.0), rn);
+    r = rn;
+    npc = npn;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// wavefront 0: right-looking elimination of the 16 columns of sub-block sb of the 64 x 64
+// diagonal tile; emits L into M (rows of the tile at and below the sub-block), W = L D of the
+// rows below the 16 x 16 pivot tile into Wt, D and 1 / D.  (Rows ABOVE the sub-block ride along
+// with zeros, and the pivot rows ride along as copies of themselves: what they store above the
+// diagonal of the tile is never read.)
+__device__ __forceinline__ void chain_a_plus(double (*M)[C_LD], double (*Wt)[C_WLD], double *dD,
+                                             double *dI, int &s_bad, int lane, int sb, int ncol,
+                                             double (*Lt)[16]) {
+  (void)Lt;
+  const int cb = sb * 16, prow = lane & 15;
+  double a[16], b[16];
+#pragma unroll
+  for (int k = 0; k < 16; k += 2) {
+    const double2_t v = *reinterpret_cast<const double2_t *>(&M[cb + prow][cb + k]);
+    const double2_t u = *reinterpret_cast<const double2_t *>(&M[lane][cb + k]);
+    a[k] = v.x;
+    a[k + 1] = v.y;
+    b[k] = u.x;
+    b[k + 1] = u.y;
+  }
+  double r = __builtin_amdgcn_rcp(a[0]);
+  r = fma(r, fma(-a[0], r, 1.0), r);
+  double npc = -a[0] * dpp_bcast<1>(a[0]);
+  double dmine = 1.0;
+  double *mrow = &M[lane][cb], *wrow = &Wt[lane][0];
+  chain_a_col<0>(a, b, r, npc, dmine, prow, mrow, wrow);
+  chain_a_col<1>(a, b, r, npc, dmine, prow, mrow, wrow);
+  chain_a_col<2>(a, b, r, npc, dmine, prow, mrow, wrow);
+  chain_a_col<3>(a, b, r, npc, dmine, prow, mrow, wrow);
+  chain_a_col<4>(a, b, r, npc, dmine, prow, mrow, wrow);
+  chain_a_col<5>(a, b, r, npc, dmine, prow, mrow, wrow);
+  chain_a_col<6>(a, b, r, npc, dmine, prow, mrow, wrow);
+  chain_a_col<7>(a, b, r, npc, dmine, prow, mrow, wrow);
+  chain_a_col<8>(a, b, r, npc, dmine, prow, mrow, wrow);
+  chain_a_col<9>(a, b, r, npc, dmine, prow, mrow, wrow);
+  chain_a_col<10>(a, b, r, npc, dmine, prow, mrow, wrow);
+  chain_a_col<11>(a, b, r, npc, dmine, prow, mrow, wrow);
+  chain_a_col<12>(a, b, r, npc, dmine, prow, mrow, wrow);
+  chain_a_col<13>(a, b, r, npc, dmine, prow, mrow, wrow);
+  chain_a_col<14>(a, b, r, npc, dmine, prow, mrow, wrow);
+  chain_a_col<15>(a, b, r, npc, dmine, prow, mrow, wrow);
+  const int tr = lane - cb;  // row inside the 16 x 16 pivot tile
+  const bool piv = tr >= 0 && tr < 16;
+  // classes flagged bad: sNaN, qNaN, -inf, -0, +0, +inf
+  const bool isbad = __builtin_amdgcn_class(dmine, 0x1 | 0x2 | 0x4 | 0x20 | 0x40 | 0x200);
+  const bool bad_any = __ballot(piv && isbad && lane < ncol) != 0ull;
+  if (piv) {
+    M[lane][lane] = dmine;  // (behind the riding copy's store of a 1 at this place)
+    dD[lane] = dmine;
+    dI[lane] = isbad ? 0.0 : fast_recip(dmine);
+    if (tr == 0 && bad_any) s_bad = 1;
+  }
+}
+
+// one lane per stack row below the diagonal tile: x L_bb^T = a_row for sub-block sbp; X (= L D)
+// replaces the row's entries in place.  The lane holds pivot row (lane & 15) of W = L D of the
+// factored tile (from M and D: chain_a_plus left L below the tile's diagonal), the multipliers
+// come as DPP broadcasts: x[K] -= (x[C] / d_C) * W[K][C].
+template <int C>
+__device__ __forceinline__ void chain_b_col(double (&x)[16], const double (&w)[16], double di) {
+  const double m = -x[C] * dpp_bcast<C>(di);
+#define CH_UX(K) \
+  if (K > C) dpp_fmac<K>(x[K], w[C], m);
+  CH_UX(1) CH_UX(2) CH_UX(3) CH_UX(4) CH_UX(5) CH_UX(6) CH_UX(7) CH_UX(8) CH_UX(9) CH_UX(10)
+  CH_UX(11) CH_UX(12) CH_UX(13) CH_UX(14) CH_UX(15)
+#undef CH_UX
+  __builtin_amdgcn_sched_barrier(0);  // eager (right-looking) order, see chain_a_plus
+}
+__device__ __forceinline__ void chain_b_own(double (*M)[C_LD], int row, int sbp, int lane,
+                                            const double (*Lt)[16], const double *dD, const double *dI) {
+  (void)Lt;
+  const int cb = sbp * 16, prow = lane & 15;
+  double x[16], w[16];
+#pragma unroll
+  for (int k = 0; k < 16; k += 2) {
+    const double2_t v = *reinterpret_cast<const double2_t *>(&M[row][cb + k]);
+    const double2_t l = *reinterpret_cast<const double2_t *>(&M[cb + prow][cb + k]);
+    const double2_t d = *reinterpret_cast<const double2_t *>(&dD[cb + k]);
+    x[k] = v.x;
+    x[k + 1] = v.y;
+    w[k] = l.x * d.x;  // (entries on and above the diagonal: D itself or junk, never broadcast)
+    w[k + 1] = l.y * d.y;
+  }
+  const double di = dI[cb + prow];
+  chain_b_col<0>(x, w, di);
+  chain_b_col<1>(x, w, di);
+  chain_b_col<2>(x, w, di);
+  chain_b_col<3>(x, w, di);
+  chain_b_col<4>(x, w, di);
+  chain_b_col<5>(x, w, di);
+  chain_b_col<6>(x, w, di);
+  chain_b_col<7>(x, w, di);
+  chain_b_col<8>(x, w, di);
+  chain_b_col<9>(x, w, di);
+  chain_b_col<10>(x, w, di);
+  chain_b_col<11>(x, w, di);
+  chain_b_col<12>(x, w, di);
+  chain_b_col<13>(x, w, di);
+  chain_b_col<14>(x, w, di);
+#pragma unroll
+  for (int k = 0; k < 16; k += 2) {
+    double2_t wv;
+    wv.x = x[k];
+    wv.y = x[k + 1];
+    *reinterpret_cast<double2_t *>(&M[row][cb + k]) = wv;
+  }
+}
+#else
 // wavefront 0: right-looking elimination of the 16 columns of sub-block sb of the 64 x 64
 // diagonal tile, lane <-> row (the scheme of panel_body's (a+), pgf_ldlt.hip): the tile's rows
 // and, in the same instruction stream, the tile rows below it; emits L into M, W = L D of the
@@ -453,7 +631,7 @@ __device__ __forceinline__ void chain_b_col(double (&x)[16], unsigned base) {
   __builtin_amdgcn_sched_barrier(0);  // eager (right-looking) order, see chain_a_plus
 }
 __device__ __forceinline__ void chain_b_own(double (*M)[C_LD], int row, int sbp, int lane,
-                                            const double (*Lt)[16]) {
+                                            const double (*Lt)[16], const double *, const double *) {
   const int cb = sbp * 16;
   double x[16];
 #pragma unroll
@@ -486,6 +664,7 @@ __device__ __forceinline__ void chain_b_own(double (*M)[C_LD], int row, int sbp,
     *reinterpret_cast<double2_t *>(&M[row][cb + k]) = wv;
   }
 }
+#endif  // PGF_CHAIN_DPP
 
 // C (16 x 16 at M[ci][cj]) -= A B^T over 16 k: A rows at (ar, ak) of Am (stride lda doubles),
 // B rows at M[br][bk]
@@ -986,7 +1165,7 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
         // previous sub-panel's in-block update already)
         if (!(early0 && sb == 0)) chain_a_plus(M, Wt + (sb & 1) * 64, dD, dI, s_bad, lane, sb, ncol, Lt[sb & 1]);
       } else if (wave <= 3) {
-        if (sb > 0 && 64 * (wave - 1) < own) chain_b_own(M, 64 * wave + lane, sb - 1, lane, Lt[(sb - 1) & 1]);
+        if (sb > 0 && 64 * (wave - 1) < own) chain_b_own(M, 64 * wave + lane, sb - 1, lane, Lt[(sb - 1) & 1], dD, dI);
       } else {
         // deferred tiles: diagonal (ti, tj), tj in [sb + 1, 3], of step sb - 1; lower (ti, tj),
         // tj in [sb, 3], of step sb - 2
@@ -1087,7 +1266,7 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
         }
       }
       if (s == 0) CH_STAMP();  // C loads issued
-      if (wave >= 1 && wave <= 3 && 64 * (wave - 1) < own) chain_b_own(M, 64 * wave + lane, 3, lane, Lt[1]);
+      if (wave >= 1 && wave <= 3 && 64 * (wave - 1) < own) chain_b_own(M, 64 * wave + lane, 3, lane, Lt[1], dD, dI);
       for (int p = tid; p < 64 * 64; p += NT) {
         const int row = p >> 6, c = p & 63;
         if (c <= row) K[(int64_t)(cb + row) * ldk + cb + c] = M[row][c];
@@ -1179,7 +1358,7 @@ __device__ __forceinline__ void chain_body(unsigned char *smem, double *K, int64
       preloaded = true;
       early0 = true;
     } else {
-      if (wave >= 1 && wave <= 3 && 64 * (wave - 1) < own) chain_b_own(M, 64 * wave + lane, 3, lane, Lt[1]);
+      if (wave >= 1 && wave <= 3 && 64 * (wave - 1) < own) chain_b_own(M, 64 * wave + lane, 3, lane, Lt[1], dD, dI);
       __syncthreads();
       CH_STAMP();  // panel factored
 #pragma unroll
