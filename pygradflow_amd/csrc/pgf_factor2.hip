@@ -1509,7 +1509,9 @@ __global__ __launch_bounds__(64 * NW) void k_diag_chain(double *K, int64_t ldk, 
 // rowstart (or the diagonal, whichever is lower) -- from "blocks < kc0 / 256 applied" to
 // "blocks < (kc0 + KB) / 256 applied"; its 128 x 128 tiles are numbered tile_begin[q] ...
 #define UPD_MAXJOBS 96
-#define UPD_TM 128  // tile rows (x 128 columns); 64 measured the same (finer rounds, less reuse)
+#define UPD_TM 64  // tile rows (x 128 columns): with the persistent tile loop below the finer unit packs
+                   // a launch's work into fewer idle CU-rounds (128: ~260 units of 37 us over 253 CUs = two
+                   // rounds, half of the second one idle)
 struct UpdJobs {
   int njobs;
   int tile_begin[UPD_MAXJOBS + 1];
@@ -1544,6 +1546,25 @@ __device__ __forceinline__ void update_job_tile(unsigned char *smem, int t, doub
                                               nrows, N, kc0, jobs.KB[q], dvec + kc0);
 }
 
+// The update role, persistent: a workgroup takes tile after tile of the launch's job table from an
+// atomic counter (zeroed with the factorisation's flags) until the table is exhausted -- deepest
+// jobs first, so the long tiles start early and the short ones fill the gaps (round 2: one tile
+// per workgroup; ~260 tiles over 253 CUs ran as two rounds, the second nearly empty).
+__device__ __forceinline__ void update_worker(unsigned char *smem, double *K, int64_t ldk,
+                                              const double *__restrict__ dvec, int N, int nrows,
+                                              const UpdJobs &jobs, int *ctr) {
+  __shared__ int s_next;
+  const int total = jobs.tile_begin[jobs.njobs];
+  for (;;) {
+    if (threadIdx.x == 0) s_next = atomicAdd(ctr, 1);
+    __syncthreads();
+    const int t = s_next;
+    __syncthreads();  // (s_next is rewritten next round; the previous tile's LDS reads are done)
+    if (t >= total) return;
+    update_job_tile(smem, t, K, ldk, dvec, N, nrows, jobs);
+  }
+}
+
 template <bool HELP>
 __global__ __launch_bounds__(1024) void k_chain_update(double *K, int64_t ldk, int c0, int nb,
                                                        double *__restrict__ dvec,
@@ -1552,7 +1573,7 @@ __global__ __launch_bounds__(1024) void k_chain_update(double *K, int64_t ldk, i
                                                        double *__restrict__ Linv,
                                                        double *__restrict__ LinvT, int *hc,
                                                        int epoch, int N, int nrows,
-                                                       const UpdJobs jobs) {
+                                                       const UpdJobs jobs, int *ctr) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[CH_SMEM];
   const int b = (int)blockIdx.x;
   if (b == 0) {
@@ -1567,15 +1588,15 @@ __global__ __launch_bounds__(1024) void k_chain_update(double *K, int64_t ldk, i
     helper_inverses<16>(smem, K, ldk, c0, nb, hc, epoch, flags, Linv, LinvT);
     return;
   }
-  update_job_tile(smem, b - 1 - (HELP ? (b > 8) + (b > 16) : 0), K, ldk, dvec, N, nrows, jobs);
+  update_worker(smem, K, ldk, dvec, N, nrows, jobs, ctr);
 }
 
 // the update role alone (per-kernel profiling, PGF_FUSED=0): same tiles, same job table
 __global__ __launch_bounds__(1024) void k_update_jobs(double *K, int64_t ldk,
                                                       const double *__restrict__ dvec, int N,
-                                                      int nrows, const UpdJobs jobs) {
+                                                      int nrows, const UpdJobs jobs, int *ctr) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 256 * 34 * 8];
-  update_job_tile(smem, (int)blockIdx.x, K, ldk, dvec, N, nrows, jobs);
+  update_worker(smem, K, ldk, dvec, N, nrows, jobs, ctr);
 }
 
 // ------------------------------------------------------------------ batched wrappers
@@ -1592,14 +1613,14 @@ __global__ __launch_bounds__(1024) void k_chain3_update(double *K, int64_t ldk, 
                                                         double *__restrict__ dvec, double *__restrict__ dinv,
                                                         int *__restrict__ flags, double *__restrict__ Linv,
                                                         double *__restrict__ LinvT, int N, int nrows,
-                                                        const UpdJobs jobs) {
+                                                        const UpdJobs jobs, int *ctr) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[CH_SMEM];
   const int b = (int)blockIdx.x;
   if (b == 0) {
     chain3_body(smem, K, ldk, c0, nb, dvec, dinv, flags, Linv, LinvT, nullptr);
     return;
   }
-  update_job_tile(smem, b - 1, K, ldk, dvec, N, nrows, jobs);
+  update_worker(smem, K, ldk, dvec, N, nrows, jobs, ctr);
 }
 
 template <bool HELP>
@@ -1902,7 +1923,7 @@ static void plan_updates(UpdPlan &pl, int N, int nrows, int OB, int budget, int 
     }
     // list-scheduling estimate of the launch: work / 255 CUs, at least the deepest tile, in
     // whole tile times; and never less than the chain
-    const double t = std::max((double)maxdepth, std::ceil(units / 255.0));
+    const double t = std::max((double)maxdepth, std::ceil(units / 253.0));
     pl.cost += std::max(chain_units, t);
   }
 }
@@ -1911,8 +1932,16 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
   f.N = N;
   f.factored = false;
   hipStream_t s = f.stream;
-  hipError_t e = hipMemsetAsync(f.flags, 0, 4 * sizeof(int), s);
+  // flags [0, 4) and the update launches' tile counters behind them
+  hipError_t e = hipMemsetAsync(f.flags, 0, (4 + LDLT_UPD_COUNTERS) * sizeof(int), s);
   if (e != hipSuccess) return e;
+  static const int ncu = []() {
+    int dev = 0, n = 256;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+      n = pr.multiProcessorCount;
+    return n;
+  }();
   PgfProfile *p = (f.prof && f.prof->enabled) ? f.prof : nullptr;
   if (p) {
     p->factor_spans.emplace_back(prof_event(p), prof_event(p));
@@ -1941,7 +1970,7 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
       none.njobs = 0;
       none.tile_begin[0] = 0;
       hipLaunchKernelGGL(k_chain3_update, dim3(1), dim3(1024), 0, s, f.K, f.ldk, c0, nb, f.dvec, f.dinv,
-                         f.flags, f.Linv, f.LinvT, N, nrows, none);
+                         f.flags, f.Linv, f.LinvT, N, nrows, none, f.flags + 4);
     } else if (chain_waves() == 16) {
       if (help)
         hipLaunchKernelGGL((k_diag_chain<16, true>), dim3(17), dim3(1024), 0, s, f.K, f.ldk, c0, nb,
@@ -1996,7 +2025,8 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
     static thread_local UpdPlan cplan;
     if (cN != N || cR != nrows) {
       // ~86 us chain / time of one tile-block (64 x 128 x 256: ~21 us, 128 x 128: ~40 us)
-      const double chain_units = 86.0 / (UPD_TM == 64 ? 21.0 : 40.0);
+      // ~66 us chain (DPP elimination) / time of one tile-block (64 x 128 x 256: ~21 us, 128 x 128: ~40 us)
+      const double chain_units = 66.0 / (UPD_TM == 64 ? 21.0 : 40.0);
       if (getenv("PGF_LAZY_BUDGET")) {
         plan_updates(cplan, N, nrows, OB, lazy_budget(), lazy_cap(), chain_units);
       } else {
@@ -2071,17 +2101,19 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
         p->fused_flops.push_back(fl);
         p->fused_bytes.push_back(by);
       }
+      int *ctr = f.flags + 4 + ((c0 / OB + 1) % LDLT_UPD_COUNTERS);
+      const int workers = std::min(ntiles, ncu - 3);  // one workgroup per CU: persistent tile loops
       if (chain3_on())
-        hipLaunchKernelGGL(k_chain3_update, dim3(1 + ntiles), dim3(1024), 0, s, f.K, f.ldk, c1, nb1,
-                           f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, N, nrows, js);
+        hipLaunchKernelGGL(k_chain3_update, dim3(1 + workers), dim3(1024), 0, s, f.K, f.ldk, c1, nb1,
+                           f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, N, nrows, js, ctr);
       else if (help)
-        hipLaunchKernelGGL(k_chain_update<true>, dim3(std::max(17, ntiles + 3)), dim3(1024), 0, s,
+        hipLaunchKernelGGL(k_chain_update<true>, dim3(std::max(17, workers + 3)), dim3(1024), 0, s,
                            f.K, f.ldk, c1, nb1, f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, f.hctl, ep,
-                           N, nrows, js);
+                           N, nrows, js, ctr);
       else
-        hipLaunchKernelGGL(k_chain_update<false>, dim3(1 + ntiles), dim3(1024), 0, s, f.K, f.ldk,
+        hipLaunchKernelGGL(k_chain_update<false>, dim3(1 + workers), dim3(1024), 0, s, f.K, f.ldk,
                            c1, nb1, f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, f.hctl, ep, N, nrows,
-                           js);
+                           js, ctr);
       if (prod) span_end(pr.fused_spans);
     } else {
       launch_d(c1);
@@ -2094,8 +2126,8 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
           e1 = prof_event(p);
           (void)hipEventRecord(e0, s);
         }
-        hipLaunchKernelGGL(k_update_jobs, dim3(ntiles), dim3(1024), 0, s, f.K, f.ldk, f.dvec, N, nrows,
-                           js);
+        hipLaunchKernelGGL(k_update_jobs, dim3(std::min(ntiles, ncu)), dim3(1024), 0, s, f.K, f.ldk,
+                           f.dvec, N, nrows, js, f.flags + 4 + ((c0 / OB + 1) % LDLT_UPD_COUNTERS));
         if (p) {
           (void)hipEventRecord(e1, s);
           p->update_spans.emplace_back(e0, e1);

@@ -36,6 +36,10 @@ struct PgfProfile {
 // Dense symmetric factor  K = L D L^T  (unit lower L, diagonal D), lower triangle,
 // row-major in HBM with row stride ldk.  Row N (when nrows == N + 1) carries a
 // right-hand side through the elimination (forward substitution for free).
+// update launches of one factorisation that can have their own persistent-tile counter (behind
+// flags[0..3]; reused modulo this number: a launch is long finished 256 launches later)
+#define LDLT_UPD_COUNTERS 256
+
 struct DenseLdlt {
   int Nmax = 0;
   int64_t ldk = 0;

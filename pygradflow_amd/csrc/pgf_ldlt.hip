@@ -1344,7 +1344,8 @@ hipError_t ldlt_alloc(DenseLdlt &f, int Nmax, hipStream_t stream) {
   if ((e = hipMalloc(&f.zwork, rows * sizeof(double))) != hipSuccess) return e;
   if ((e = hipMalloc(&f.Linv, (rows / 64 + 1) * 4096 * sizeof(double))) != hipSuccess) return e;
   if ((e = hipMalloc(&f.LinvT, (rows / 64 + 1) * 4096 * sizeof(double))) != hipSuccess) return e;
-  if ((e = hipMalloc(&f.flags, 4 * sizeof(int))) != hipSuccess) return e;
+  if ((e = hipMalloc(&f.flags, (4 + LDLT_UPD_COUNTERS) * sizeof(int))) != hipSuccess) return e;
+  if ((e = hipMemset(f.flags, 0, (4 + LDLT_UPD_COUNTERS) * sizeof(int))) != hipSuccess) return e;
   f.chain_stride = (int)(rows / 64 + 2);
   if ((e = hipMalloc(&f.chain, (2 * f.chain_stride + 4) * sizeof(int))) != hipSuccess) return e;
   if ((e = hipMemset(f.chain, 0, (2 * f.chain_stride + 4) * sizeof(int))) != hipSuccess) return e;
