@@ -276,7 +276,7 @@ int pgf_batch_profile_read(pgf_batch b, double *update_ms, int64_t *update_launc
  * (linear_solver/linear_solver.py:18-21, lu_solver.py:9-17).  A: dense row-major N x N.
  * symmetric != 0: LDL^T on the lower triangle; symmetric == 0: LU with partial pivoting of the
  * full matrix (what the reference's LUSolver does for every matrix; needed by its Standard /
- * Extended / Asymmetric step-solver formulations, step/solver/*.py).  PGF_SINGULAR on failure.
+ * Extended / Asymmetric step-solver formulations, step/solver/).  PGF_SINGULAR on failure.
  * pgf_ls_solve(trans != 0) solves with A^T (cond_estimate.py:82).  pgf_ls_num_neg: LDL^T only
  * (PGF_NOT_READY for an LU: LUSolver.num_neg_eigvals() is None).  pgf_ls_get_factor copies
  * L below / D on the diagonal, or for the LU: unit-lower L below, U on and above. */

@@ -72,6 +72,11 @@ struct pgf_solver {
   bool sp_guarded = false;  // banded path: the last solve carried the residual check (k_band_residual)
   double *h_bred = nullptr;  // pinned mirror of sp.bred
   bool sp_stat_pending = false;  // a guarded banded step's status block is on its way to h_bred
+  // the current dense factor is that of the condensed system (constraint block eliminated
+  // first, condensed_wanted below); cd_t: its right-hand side
+  bool condensed = false;
+  bool condensed_veto = false;  // it met a zero pivot: natural order until the matrix changes
+  double *cd_t = nullptr;
 };
 
 struct pgf_linsolver {
@@ -169,6 +174,7 @@ int pgf_create(int n, int m, int device, unsigned flags, pgf_handle *out) {
   A_(red, (N + 255) / 256 + 1) A_(scal, 4) A_(meas, 4 * ((N + 255) / 256) + 4);
   if (!sparse) {
     A_(rs_v, n) A_(rs_lv, n) A_(rs_u, n) A_(rs_wy, m) A_(rs_r, N + 1) A_(rs_d, N + 1) A_(rs_red, 8);
+    A_(cd_t, n + 1);
   }
   A_(mask, n) A_(mask_new, n) A_(idxI, n) A_(idxA, n) A_(pos, n) A_(counts, 4);
 #undef A_
@@ -209,7 +215,7 @@ int pgf_destroy(pgf_handle h) {
                   h->rhs,  h->sol,  h->dx,  h->dy,   h->q,    h->b,        h->w,    h->tmpn,
                   h->partial, h->red, h->scal, h->mask, h->mask_new, h->idxI, h->idxA, h->pos,
                   h->counts, h->meas, h->rs_v, h->rs_lv, h->rs_u, h->rs_wy, h->rs_r, h->rs_d,
-                  h->rs_red};
+                  h->rs_red, h->cd_t};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h->h_rs) (void)hipHostFree(h->h_rs);
@@ -256,6 +262,7 @@ static int down(pgf_handle h, void *dst, const void *src, size_t bytes) {
 
 static void invalidate_factor(pgf_handle h) {
   h->fac.factored = false;
+  h->condensed_veto = false;
   h->lu_active = false;
   h->factor_clean = false;
 }
@@ -485,6 +492,86 @@ static void assemble(pgf_handle h, double *K, int64_t ldk) {
                       h->delta);
 }
 
+// ---- the condensed system ------------------------------------------------------------------
+// K = [[A, J_I^T], [J_I, -delta I]], A = H[I,I] + lamb I.  Pivoting on the constraint block first
+// (it is diagonal: nothing to factorise) leaves the nI x nI Schur complement S = A + J_I^T J_I /
+// delta: m fewer pivots on the serial diagonal chain -- 16 column blocks instead of 20 at
+// n = 4096, m = 1024 -- and N^3/3 -> nI^3/3 + nI^2 m flops, the second term as one more pending
+// rank-m update of the look-ahead schedule (DenseLdlt::V, pgf_factor2.hip).  Same LDL^T of the
+// same matrix in another (symmetric) pivot order; inertia = m + that of S.
+//   S s_x = b_x + J_I^T b_y / delta,   s_y = (J_I s_x - b_y) / delta.
+// The order is only stable while the eliminated block does not dwarf A: the growth
+// ||J_I^T J_I / delta|| / ||A|| is bounded by g = ||J||_1 ||J||_inf / (delta (||H||_inf + lamb));
+// beyond PGF_CONDENSED_GROWTH (default 1e3) the natural order is kept.  The residual guard
+// (refine_if_needed) sees the full K either way.
+// PGF_CONDENSED: 0 never, 1 (default) when it saves a column block, 2 whenever the growth allows
+// (tests: the small golden cases).
+static int residual_norms(pgf_handle h);
+static int condensed_mode() {
+  static const int v = []() {
+    const char *e = getenv("PGF_CONDENSED");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
+static bool condensed_wanted(pgf_handle h) {
+  const int mode = condensed_mode();
+  if (!mode || h->condensed_veto || h->sparse || h->m == 0 || h->nI == 0 || h->m > h->n) return false;
+  if (!ldlt_use_lookahead()) return false;
+  if (mode == 1 && (h->m < 64 || (h->N + 255) / 256 <= (h->nI + 255) / 256)) return false;
+  if (residual_norms(h)) return false;
+  static const double gmax = []() {
+    const char *e = getenv("PGF_CONDENSED_GROWTH");
+    return e ? atof(e) : 1e3;
+  }();
+  const double nH = h->h_rs[4] + h->lamb, g = h->h_rs[6] * h->h_rs[5];
+  return g <= gmax * h->delta * nH;
+}
+static hipError_t condensed_reserve(pgf_handle h) {
+  DenseLdlt &f = h->fac;
+  const int mp = (h->m + 31) / 32 * 32;
+  const size_t need = (size_t)(h->n + 1) * mp;
+  hipError_t e = hipSuccess;
+  if (f.vcap < need) {
+    if (f.V) (void)hipFree(f.V);
+    f.V = nullptr;
+    f.vcap = 0;
+    if ((e = hipMalloc((void **)&f.V, need * sizeof(double))) != hipSuccess) return e;
+    f.vcap = need;
+  }
+  if (f.vdcap < (size_t)mp) {
+    if (f.vd) (void)hipFree(f.vd);
+    f.vd = nullptr;
+    f.vdcap = 0;
+    if ((e = hipMalloc((void **)&f.vd, (size_t)mp * sizeof(double))) != hipSuccess) return e;
+    f.vdcap = mp;
+  }
+  return e;
+}
+
+// sol <- K^{-1} rhs with the current LDL^T factor (rhs, sol: N-vectors in the order
+// [inactive variables; constraints]; rhs != sol)
+static hipError_t kkt_solve_async(pgf_handle h, const double *rhs, double *sol) {
+  if (!h->condensed) return ldlt_solve_async(h->fac, rhs, sol);
+  DenseLdlt &f = h->fac;
+  launch_cond_rhs(h->stream, h->nI, h->m, f.V, f.ldv, rhs, h->delta, h->cd_t);
+  hipError_t e = ldlt_solve_async(f, h->cd_t, sol);
+  if (e != hipSuccess) return e;
+  launch_cond_y(h->stream, h->nI, h->m, f.V, f.ldv, sol, rhs + h->nI, h->delta, h->partial, PGF_GEMVT_PARTS,
+                sol + h->nI);
+  return hipGetLastError();
+}
+// the backward half for the right-hand side h->rhs that rode through the factorisation
+static hipError_t kkt_backsolve_async(pgf_handle h, double *sol) {
+  DenseLdlt &f = h->fac;
+  if (!h->condensed) return ldlt_backsolve_async(f, f.K + (int64_t)h->N * f.ldk, sol);
+  hipError_t e = ldlt_backsolve_async(f, f.K + (int64_t)h->nI * f.ldk, sol);
+  if (e != hipSuccess) return e;
+  launch_cond_y(h->stream, h->nI, h->m, f.V, f.ldv, sol, h->rhs + h->nI, h->delta, h->partial,
+                PGF_GEMVT_PARTS, sol + h->nI);
+  return hipGetLastError();
+}
+
 // enqueue assemble + factor; with_rhs: carry h->rhs through the elimination in row N
 static int factor_async(pgf_handle h, bool with_rhs) {
   if (h->sparse) {
@@ -504,6 +591,24 @@ static int factor_async(pgf_handle h, bool with_rhs) {
     return PGF_OK;
   }
   h->lu_active = false;
+  h->condensed = condensed_wanted(h);
+  h->fac.vdepth = 0;
+  if (h->condensed) {
+    DenseLdlt &f = h->fac;
+    HIPCHK(h, condensed_reserve(h));
+    const int nI = h->nI, mp = (h->m + 31) / 32 * 32;
+    f.ldv = mp;
+    f.vdepth = mp;
+    f.vneg = h->m;  // the eliminated block is -delta I
+    // A = H[I,I] + lamb I (the assembly kernel with no constraint rows), V = J_I^T, b_y in row nI
+    launch_assemble_kkt(h->stream, f.K, f.ldk, h->H, h->ldh, h->J, h->ldj, h->idxI, nI, 0, h->lamb, h->delta);
+    launch_cond_panel(h->stream, f.V, f.ldv, mp, f.vd, h->J, h->ldj, h->idxI, nI, h->m, h->delta,
+                      with_rhs ? h->rhs + nI : nullptr);
+    if (with_rhs) launch_copy(h->stream, f.K + (int64_t)nI * f.ldk, h->rhs, nI);
+    HIPCHK(h, ldlt_factor_async(f, nI, nI + (with_rhs ? 1 : 0)));
+    f.N = nI;
+    return PGF_OK;
+  }
   assemble(h, h->fac.K, h->fac.ldk);
   if (with_rhs && h->N > 0)
     launch_copy(h->stream, h->fac.K + (int64_t)h->N * h->fac.ldk, h->rhs, h->N);
@@ -512,8 +617,19 @@ static int factor_async(pgf_handle h, bool with_rhs) {
 }
 
 // internal: the factorisation just awaited must be repeated (its chain helpers failed their
-// hand-over checks and are switched off now, ldlt_finish); never leaves the library
+// hand-over checks and are switched off now, ldlt_finish -- or the condensed pivot order met a
+// zero pivot the natural order may not have: S = A + J^T J / delta can cancel exactly where no
+// pivot of K does); never leaves the library
 #define PGF_RETRY_FACTOR (-2)
+static int finish_factor_state(pgf_handle h, hipError_t *e) {
+  const int st = ldlt_finish(h->fac, e);
+  if (st == 1 && h->condensed && !h->condensed_veto) {
+    h->condensed_veto = true;
+    h->fac.factored = false;
+    return 2;
+  }
+  return st;
+}
 static const char *k_helper_msg =
     "the dense factorisation failed its hand-over checks with and without helper workgroups";
 
@@ -535,7 +651,7 @@ static int factor_finish(pgf_handle h) {
   int rcs;
   if ((rcs = sparse_status_sync(h))) return rcs;
   hipError_t e;
-  const int st = ldlt_finish(h->fac, &e);
+  const int st = finish_factor_state(h, &e);
   if (st < 0) return hip_fail(h, e, "factor");
   if (st == 2) return PGF_RETRY_FACTOR;
   if (st == 1) return fail(h, PGF_SINGULAR, "zero or non-finite pivot in LDL^T of the KKT matrix");
@@ -642,7 +758,7 @@ static int refine_if_needed(pgf_handle h, bool swapped, bool with_step = true) {
     return PGF_OK;
   };
   for (int it = 0; it < 2 && rel > h->refine_tol && rel < 1.0 && !h->lu_active; ++it) {
-    HIPCHK(h, ldlt_solve_async(h->fac, h->rs_r, h->rs_d));
+    HIPCHK(h, kkt_solve_async(h, h->rs_r, h->rs_d));
     launch_axpy1(s, h->N, h->rs_d, h->sol);
     if ((rc = finish_round())) return rc;
     ++h->stat_refined;
@@ -756,9 +872,9 @@ static int chain_recover(pgf_handle h, bool swapped) {
     std::swap(h->y, h->yn);
   }
   if (h->last_solve == 1)
-    HIPCHK(h, ldlt_backsolve_async(h->fac, h->fac.K + (int64_t)h->N * h->fac.ldk, h->sol));
+    HIPCHK(h, kkt_backsolve_async(h, h->sol));
   else
-    HIPCHK(h, ldlt_solve_async(h->fac, h->rhs, h->sol));
+    HIPCHK(h, kkt_solve_async(h, h->rhs, h->sol));
   enqueue_residual(h);
   enqueue_step_update(h);
   if (swapped) {
@@ -857,13 +973,13 @@ static int newton_core_async(pgf_handle h, bool *did_factor) {
     *did_factor = true;
     h->last_solve = 1;
     h->lu_active = false;
-    HIPCHK(h, ldlt_backsolve_async(h->fac, h->fac.K + (int64_t)h->N * h->fac.ldk, h->sol));
+    HIPCHK(h, kkt_backsolve_async(h, h->sol));
   } else {
     h->last_solve = 2;
     if (h->lu_active)
       HIPCHK(h, lu_solve_async(h->lu, h->rhs, h->sol, 0));
     else
-      HIPCHK(h, ldlt_solve_async(h->fac, h->rhs, h->sol));
+      HIPCHK(h, kkt_solve_async(h, h->rhs, h->sol));
   }
   enqueue_residual(h, !*did_factor);
   enqueue_step_update(h);
@@ -999,11 +1115,11 @@ int pgf_linear_solve(pgf_handle h, const double *rhs, int trans, double *sol) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PGF_OK;
   }
-  HIPCHK(h, ldlt_solve_async(h->fac, h->rhs, h->sol));
+  HIPCHK(h, kkt_solve_async(h, h->rhs, h->sol));
   enqueue_residual(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (ldlt_chain_check(h->fac)) {  // the chain is off now: once more with the per-block kernels
-    HIPCHK(h, ldlt_solve_async(h->fac, h->rhs, h->sol));
+    HIPCHK(h, kkt_solve_async(h, h->rhs, h->sol));
     enqueue_residual(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (ldlt_chain_check(h->fac)) return fail(h, PGF_HIP_ERROR, k_chain_msg);
@@ -1333,7 +1449,7 @@ int pgf_qp_sync(pgf_handle h, int *n_neg, double *diff) {
   hipError_t e;
   int rc;
   if ((rc = sparse_status_sync(h))) return rc;
-  int st = ldlt_finish(h->fac, &e);  // flags are only rewritten by a factor launch
+  int st = finish_factor_state(h, &e);  // flags are only rewritten by a factor launch
   if (st == 2) {
     // the chain's helper workgroups failed their checks (off now): the step is computed again
     // from the point it started at
@@ -1344,7 +1460,7 @@ int pgf_qp_sync(pgf_handle h, int *n_neg, double *diff) {
     std::swap(h->x, h->xn);
     std::swap(h->y, h->yn);
     if ((rc = down(h, h->h_scal, h->scal, sizeof(double)))) return rc;
-    st = ldlt_finish(h->fac, &e);
+    st = finish_factor_state(h, &e);
     if (st == 2) return fail(h, PGF_HIP_ERROR, k_helper_msg);
   }
   if (st < 0) return hip_fail(h, e, "step");

@@ -1518,6 +1518,14 @@ struct UpdJobs {
   int col0[UPD_MAXJOBS], rowstart[UPD_MAXJOBS], kc0[UPD_MAXJOBS], KB[UPD_MAXJOBS];
   int ntc[UPD_MAXJOBS];  // 128-wide tile columns of the job (2 per column block; adjacent column
                          // blocks with the same K-range share a job: large N, eager plan)
+  unsigned char virt[UPD_MAXJOBS];  // the K-range lies in the pre-eliminated block's panel (UpdVirt)
+};
+// The pre-eliminated block (DenseLdlt::V): panel rows V[i][.], D-scaling vd -- a job with virt set
+// reads both operands from it instead of from columns [kc0, kc0 + KB) of K.
+struct UpdVirt {
+  const double *V;
+  int64_t ldv;
+  const double *vd;
 };
 
 // tile t of a launch's job table.  ONE 128 x 128 tile per workgroup, 16 wavefronts as 4 x 4 with
@@ -1525,7 +1533,7 @@ struct UpdJobs {
 // workgroup per CU, so the 16 wavefronts share one staged panel pair.
 __device__ __forceinline__ void update_job_tile(unsigned char *smem, int t, double *K, int64_t ldk,
                                                 const double *__restrict__ dvec, int N, int nrows,
-                                                const UpdJobs &jobs) {
+                                                const UpdJobs &jobs, const UpdVirt &uv) {
   if (t >= jobs.tile_begin[jobs.njobs]) return;
   int q = 0;
   while (t >= jobs.tile_begin[q + 1]) ++q;
@@ -1542,8 +1550,12 @@ __device__ __forceinline__ void update_job_tile(unsigned char *smem, int t, doub
   }
   i0 += UPD_TM * t;
   const int kc0 = jobs.kc0[q];
-  update_tile<UPD_TM, 128, 32, 4, 4, 1, true>(smem, threadIdx.x, i0, j0, K, ldk, K + kc0, ldk, N,
-                                              nrows, N, kc0, jobs.KB[q], dvec + kc0);
+  const bool vj = jobs.virt[q] != 0;
+  const double *Wp = vj ? uv.V + kc0 : K + kc0;
+  const int64_t ldw = vj ? uv.ldv : ldk;
+  const double *ds = vj ? uv.vd + kc0 : dvec + kc0;
+  update_tile<UPD_TM, 128, 32, 4, 4, 1, true>(smem, threadIdx.x, i0, j0, K, ldk, Wp, ldw, N, nrows, N, kc0,
+                                              jobs.KB[q], ds);
 }
 
 // The update role, persistent: a workgroup takes tile after tile of the launch's job table from an
@@ -1552,7 +1564,7 @@ __device__ __forceinline__ void update_job_tile(unsigned char *smem, int t, doub
 // per workgroup; ~260 tiles over 253 CUs ran as two rounds, the second nearly empty).
 __device__ __forceinline__ void update_worker(unsigned char *smem, double *K, int64_t ldk,
                                               const double *__restrict__ dvec, int N, int nrows,
-                                              const UpdJobs &jobs, int *ctr) {
+                                              const UpdJobs &jobs, const UpdVirt &uv, int *ctr) {
   __shared__ int s_next;
   const int total = jobs.tile_begin[jobs.njobs];
   for (;;) {
@@ -1561,7 +1573,7 @@ __device__ __forceinline__ void update_worker(unsigned char *smem, double *K, in
     const int t = s_next;
     __syncthreads();  // (s_next is rewritten next round; the previous tile's LDS reads are done)
     if (t >= total) return;
-    update_job_tile(smem, t, K, ldk, dvec, N, nrows, jobs);
+    update_job_tile(smem, t, K, ldk, dvec, N, nrows, jobs, uv);
   }
 }
 
@@ -1573,7 +1585,7 @@ __global__ __launch_bounds__(1024) void k_chain_update(double *K, int64_t ldk, i
                                                        double *__restrict__ Linv,
                                                        double *__restrict__ LinvT, int *hc,
                                                        int epoch, int N, int nrows,
-                                                       const UpdJobs jobs, int *ctr) {
+                                                       const UpdJobs jobs, const UpdVirt uv, int *ctr) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[CH_SMEM];
   const int b = (int)blockIdx.x;
   if (b == 0) {
@@ -1588,15 +1600,16 @@ __global__ __launch_bounds__(1024) void k_chain_update(double *K, int64_t ldk, i
     helper_inverses<16>(smem, K, ldk, c0, nb, hc, epoch, flags, Linv, LinvT);
     return;
   }
-  update_worker(smem, K, ldk, dvec, N, nrows, jobs, ctr);
+  update_worker(smem, K, ldk, dvec, N, nrows, jobs, uv, ctr);
 }
 
 // the update role alone (per-kernel profiling, PGF_FUSED=0): same tiles, same job table
 __global__ __launch_bounds__(1024) void k_update_jobs(double *K, int64_t ldk,
                                                       const double *__restrict__ dvec, int N,
-                                                      int nrows, const UpdJobs jobs, int *ctr) {
+                                                      int nrows, const UpdJobs jobs, const UpdVirt uv,
+                                                      int *ctr) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 256 * 34 * 8];
-  update_worker(smem, K, ldk, dvec, N, nrows, jobs, ctr);
+  update_worker(smem, K, ldk, dvec, N, nrows, jobs, uv, ctr);
 }
 
 // ------------------------------------------------------------------ batched wrappers
@@ -1613,14 +1626,14 @@ __global__ __launch_bounds__(1024) void k_chain3_update(double *K, int64_t ldk, 
                                                         double *__restrict__ dvec, double *__restrict__ dinv,
                                                         int *__restrict__ flags, double *__restrict__ Linv,
                                                         double *__restrict__ LinvT, int N, int nrows,
-                                                        const UpdJobs jobs, int *ctr) {
+                                                        const UpdJobs jobs, const UpdVirt uv, int *ctr) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[CH_SMEM];
   const int b = (int)blockIdx.x;
   if (b == 0) {
     chain3_body(smem, K, ldk, c0, nb, dvec, dinv, flags, Linv, LinvT, nullptr);
     return;
   }
-  update_worker(smem, K, ldk, dvec, N, nrows, jobs, ctr);
+  update_worker(smem, K, ldk, dvec, N, nrows, jobs, uv, ctr);
 }
 
 template <bool HELP>
@@ -1846,14 +1859,26 @@ void ldlt_chain_timing_dump() {
 // does.  The budget is therefore chosen per factorisation: the candidate with the smallest
 // estimated total time (plan_cost) -- the reduced size changes from step to step.
 struct UpdPlan {
-  std::vector<UpdJobs> launch;  // [L - 1]
+  UpdJobs pre;                  // before the first chain (virtual blocks only; no chain beside it)
+  UpdJobs first;                // beside the chain of column block 0 (virtual blocks only)
+  std::vector<UpdJobs> launch;  // [L - 1]: beside the chain of column block k + 1
   double cost = 0.0;            // estimated sum of launch times in units of one tile-block
 };
 
-static void plan_updates(UpdPlan &pl, int N, int nrows, int OB, int budget, int cap, double chain_units) {
+// A pre-eliminated block of depth vdepth (DenseLdlt::V) counts as nv = ceil(vdepth / OB) column
+// blocks that are factorised before the first one: block indices below are unified, virtual blocks
+// [0, nv) first, real block k at nv + k.  Updates commute, so the only deadlines are the usual
+// ones -- a column block's diagonal tile complete before its chain, its rows below before its T --
+// and the virtual blocks are pending work like any other: column block 0 is due before the first
+// chain (stage `pre', the only exposed part), column block 1 beside it (`first'), the rest lazily.
+static void plan_updates(UpdPlan &pl, int N, int nrows, int OB, int budget, int cap, double chain_units,
+                         int vdepth = 0) {
   const int nblk = (N + OB - 1) / OB;
+  const int nv = (vdepth + OB - 1) / OB;
   std::vector<int> done(nblk + 2, 0);
   pl.launch.assign(std::max(0, nblk - 1), UpdJobs());
+  pl.pre.njobs = pl.first.njobs = 0;
+  pl.pre.tile_begin[0] = pl.first.tile_begin[0] = 0;
   pl.cost = 0.0;
   auto tiles = [&](int col0, int rowstart) {
     int n = 0;
@@ -1865,21 +1890,23 @@ static void plan_updates(UpdPlan &pl, int N, int nrows, int OB, int budget, int 
     }
     return n;
   };
-  for (int k = 0; k + 1 < nblk; ++k) {
-    const int c1 = (k + 1) * OB, nb1 = std::min(OB, N - c1), row0 = c1 + nb1;
+  // stage -2: pre, -1: first, k >= 0: the launch beside the chain of column block k + 1
+  for (int st = (nv > 0 ? -2 : 0); st < nblk - 1; ++st) {
+    const int k = st;
+    const int avail = st < 0 ? nv - 1 : nv + k;  // newest block whose panel exists
     UpdJobs jb;
     jb.njobs = 0;
     int units = 0, maxdepth = 0, cnt[UPD_MAXJOBS];
-    auto add = [&](int J, int rowstart, int p0, int p1) {
+    auto add1 = [&](int J, int rowstart, bool vj, int kc0, int KB, int depth) {
       const int n = tiles(J * OB, rowstart);
-      if (!n) return;
-      units += n * (p1 - p0 + 1);
-      maxdepth = std::max(maxdepth, p1 - p0 + 1);
+      if (!n || KB <= 0) return;
+      units += n * depth;
+      maxdepth = std::max(maxdepth, depth);
       // a whole column block right behind the previous job's, same K-range: one job
       if (jb.njobs > 0 && rowstart == J * OB) {
         const int q = jb.njobs - 1;
-        if (jb.rowstart[q] == jb.col0[q] && jb.col0[q] + 128 * jb.ntc[q] == J * OB &&
-            jb.kc0[q] == p0 * OB && jb.KB[q] == (p1 - p0 + 1) * OB) {
+        if (jb.rowstart[q] == jb.col0[q] && jb.col0[q] + 128 * jb.ntc[q] == J * OB && jb.kc0[q] == kc0 &&
+            jb.KB[q] == KB && (jb.virt[q] != 0) == vj) {
           jb.ntc[q] += OB / 128;
           cnt[q] += n;
           return;
@@ -1888,20 +1915,54 @@ static void plan_updates(UpdPlan &pl, int N, int nrows, int OB, int budget, int 
       const int q = jb.njobs++;
       jb.col0[q] = J * OB;
       jb.rowstart[q] = rowstart;
-      jb.kc0[q] = p0 * OB;
-      jb.KB[q] = (p1 - p0 + 1) * OB;
+      jb.kc0[q] = kc0;
+      jb.KB[q] = KB;
       jb.ntc[q] = OB / 128;
+      jb.virt[q] = vj ? 1 : 0;
       cnt[q] = n;
     };
-    if (done[k + 1] <= k) add(k + 1, row0, done[k + 1], k);
-    done[k + 1] = k + 1;
-    for (int J = k + 2; J < nblk; ++J) {
-      const int pend = k + 1 - done[J];
+    // unified blocks [p0, p1]: the virtual part and the real part are separate jobs
+    auto add = [&](int J, int rowstart, int p0, int p1) {
+      if (p1 < p0) return;
+      if (p0 < nv) {
+        const int v1 = std::min(p1, nv - 1);
+        add1(J, rowstart, true, p0 * OB, std::min((v1 + 1) * OB, vdepth) - p0 * OB, v1 - p0 + 1);
+      }
+      if (p1 >= nv) {
+        const int r0 = std::max(p0, nv) - nv, r1 = p1 - nv;
+        add1(J, rowstart, false, r0 * OB, (r1 - r0 + 1) * OB, r1 - r0 + 1);
+      }
+    };
+    int Jopt;  // first column block whose pending work is optional at this stage
+    int lim = budget;
+    if (st == -2) {
+      add(0, 0, done[0], avail);
+      done[0] = avail + 1;
+      Jopt = 1;
+      lim = std::max(units, 250 * maxdepth);  // nothing to hide behind: fill the round the tiles of
+                                              // column block 0 occupy anyway, no more
+    } else if (st == -1) {
+      if (nblk > 1) {
+        add(1, OB, done[1], avail);
+        done[1] = avail + 1;
+      }
+      Jopt = 2;
+    } else {
+      const int c1 = (k + 1) * OB, nb1 = std::min(OB, N - c1), row0 = c1 + nb1;
+      if (done[k + 1] <= avail) add(k + 1, row0, done[k + 1], avail);
+      done[k + 1] = avail + 1;
+      if (k + 2 < nblk && done[k + 2] <= avail) {
+        add(k + 2, (k + 2) * OB, done[k + 2], avail);
+        done[k + 2] = avail + 1;
+      }
+      Jopt = k + 3;
+    }
+    for (int J = Jopt; J < nblk; ++J) {
+      const int pend = avail + 1 - done[J];
       if (pend <= 0) continue;
-      const bool mand = (J == k + 2);
       // (room is kept for the jobs that must run; what is skipped here stays pending)
-      if (!mand && (units >= budget || jb.njobs >= UPD_MAXJOBS - 2)) break;
-      const int take = mand ? pend : std::min(pend, cap);
+      if (units >= lim || jb.njobs >= UPD_MAXJOBS - 4) break;
+      const int take = std::min(pend, cap);
       add(J, J * OB, done[J], done[J] + take - 1);
       done[J] += take;
     }
@@ -1909,7 +1970,7 @@ static void plan_updates(UpdPlan &pl, int N, int nrows, int OB, int budget, int 
     int order[UPD_MAXJOBS];
     for (int q = 0; q < jb.njobs; ++q) order[q] = q;
     std::stable_sort(order, order + jb.njobs, [&](int a, int b) { return jb.KB[a] > jb.KB[b]; });
-    UpdJobs &js = pl.launch[k];
+    UpdJobs &js = st == -2 ? pl.pre : st == -1 ? pl.first : pl.launch[k];
     js.njobs = jb.njobs;
     js.tile_begin[0] = 0;
     for (int q = 0; q < jb.njobs; ++q) {
@@ -1919,12 +1980,13 @@ static void plan_updates(UpdPlan &pl, int N, int nrows, int OB, int budget, int 
       js.kc0[q] = jb.kc0[o];
       js.KB[q] = jb.KB[o];
       js.ntc[q] = jb.ntc[o];
+      js.virt[q] = jb.virt[o];
       js.tile_begin[q + 1] = js.tile_begin[q] + cnt[o];
     }
-    // list-scheduling estimate of the launch: work / 255 CUs, at least the deepest tile, in
-    // whole tile times; and never less than the chain
+    // list-scheduling estimate of the launch: work / 253 CUs, at least the deepest tile, in
+    // whole tile times; and never less than the chain (stage `pre' has none)
     const double t = std::max((double)maxdepth, std::ceil(units / 253.0));
-    pl.cost += std::max(chain_units, t);
+    pl.cost += st == -2 ? t : std::max(chain_units, t);
   }
 }
 
@@ -1960,6 +2022,8 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
   PgfProfile dummy;
   PgfProfile &pr = p ? *p : dummy;
   const bool help = chain_helpers();
+  const int vdepth = f.vdepth;
+  const UpdVirt uv{f.V, f.ldv, f.vd};
   auto launch_d = [&](int c0) {
     span_begin(pr.chain_spans);
     long long *dbg = (c0 == 0) ? chain_dbg_buffer() : nullptr;
@@ -1970,7 +2034,7 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
       none.njobs = 0;
       none.tile_begin[0] = 0;
       hipLaunchKernelGGL(k_chain3_update, dim3(1), dim3(1024), 0, s, f.K, f.ldk, c0, nb, f.dvec, f.dinv,
-                         f.flags, f.Linv, f.LinvT, N, nrows, none, f.flags + 4);
+                         f.flags, f.Linv, f.LinvT, N, nrows, none, uv, f.flags + 4);
     } else if (chain_waves() == 16) {
       if (help)
         hipLaunchKernelGGL((k_diag_chain<16, true>), dim3(17), dim3(1024), 0, s, f.K, f.ldk, c0, nb,
@@ -2019,30 +2083,31 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
   const bool lazy = fused() && (!p || prod);  // one launch for chain + update; else two, same jobs
   const int nblk = (N + OB - 1) / OB;
   UpdPlan plan;
-  if (nblk > 1) {
-    // cached per (N, nrows): a Newton iteration refactorises the same size many times
-    static thread_local int cN = -1, cR = -1;
+  if (nblk > 1 || vdepth > 0) {
+    // cached per (N, nrows, depth of the pre-eliminated block): a Newton iteration refactorises
+    // the same size many times
+    static thread_local int cN = -1, cR = -1, cV = -1;
     static thread_local UpdPlan cplan;
-    if (cN != N || cR != nrows) {
+    if (cN != N || cR != nrows || cV != vdepth) {
       // ~86 us chain / time of one tile-block (64 x 128 x 256: ~21 us, 128 x 128: ~40 us)
       // ~66 us chain (DPP elimination) / time of one tile-block (64 x 128 x 256: ~21 us, 128 x 128: ~40 us)
       const double chain_units = 66.0 / (UPD_TM == 64 ? 21.0 : 40.0);
       if (getenv("PGF_LAZY_BUDGET")) {
-        plan_updates(cplan, N, nrows, OB, lazy_budget(), lazy_cap(), chain_units);
+        plan_updates(cplan, N, nrows, OB, lazy_budget(), lazy_cap(), chain_units, vdepth);
       } else {
         // the search (60 candidate plans) once per 128-row size class: the winning budget
         // depends on the tile counts, and the reduced size moves by a few rows from step to
         // step when the active set churns (config 5b: a new N every step)
         static thread_local std::unordered_map<int, int> budget_of;
-        const int key = (nrows + 127) / 128;
+        const int key = (nrows + 127) / 128 + 4096 * ((vdepth + 127) / 128);
         auto it = budget_of.find(key);
         if (it == budget_of.end()) {
           UpdPlan best;
           int best_b = 1 << 30;
-          plan_updates(best, N, nrows, OB, best_b, lazy_cap(), chain_units);  // eager
+          plan_updates(best, N, nrows, OB, best_b, lazy_cap(), chain_units, vdepth);  // eager
           for (int b = 200 * (128 / UPD_TM); b <= 1400 * (128 / UPD_TM); b += 20 * (128 / UPD_TM)) {
             UpdPlan cand;
-            plan_updates(cand, N, nrows, OB, b, lazy_cap(), chain_units);
+            plan_updates(cand, N, nrows, OB, b, lazy_cap(), chain_units, vdepth);
             if (cand.cost < best.cost - 1e-9) {
               best = std::move(cand);
               best_b = b;
@@ -2051,11 +2116,12 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
           budget_of.emplace(key, best_b);
           cplan = std::move(best);
         } else {
-          plan_updates(cplan, N, nrows, OB, it->second, lazy_cap(), chain_units);
+          plan_updates(cplan, N, nrows, OB, it->second, lazy_cap(), chain_units, vdepth);
         }
       }
       cN = N;
       cR = nrows;
+      cV = vdepth;
     }
     plan = cplan;
   }
@@ -2073,9 +2139,61 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
       by += 16.0 * cnt + 8.0 * js.KB[q] * ((double)(nrows - rs) + (double)(colEnd - col0));
     }
   };
+  // chain of column block [c1, c1 + nb1) beside the update jobs js, one launch
+  auto launch_fused = [&](int c1, int nb1, const UpdJobs &js, int *ctr) {
+    const int ntiles = js.tile_begin[js.njobs];
+    const int ep = next_help_epoch();
+    if (prod) {
+      span_begin(pr.fused_spans);
+      double fl, by;
+      job_work(js, fl, by);
+      p->fused_flops.push_back(fl);
+      p->fused_bytes.push_back(by);
+    }
+    const int workers = std::min(ntiles, ncu - 3);  // one workgroup per CU: persistent tile loops
+    if (chain3_on())
+      hipLaunchKernelGGL(k_chain3_update, dim3(1 + workers), dim3(1024), 0, s, f.K, f.ldk, c1, nb1, f.dvec,
+                         f.dinv, f.flags, f.Linv, f.LinvT, N, nrows, js, uv, ctr);
+    else if (help)
+      hipLaunchKernelGGL(k_chain_update<true>, dim3(std::max(17, workers + 3)), dim3(1024), 0, s, f.K, f.ldk,
+                         c1, nb1, f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, f.hctl, ep, N, nrows, js, uv, ctr);
+    else
+      hipLaunchKernelGGL(k_chain_update<false>, dim3(1 + workers), dim3(1024), 0, s, f.K, f.ldk, c1, nb1,
+                         f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, f.hctl, ep, N, nrows, js, uv, ctr);
+    if (prod) span_end(pr.fused_spans);
+  };
+  // update jobs alone
+  auto launch_jobs = [&](const UpdJobs &js, int *ctr) {
+    const int ntiles = js.tile_begin[js.njobs];
+    if (ntiles <= 0) return;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (p && !prod) {
+      e0 = prof_event(p);
+      e1 = prof_event(p);
+      (void)hipEventRecord(e0, s);
+    }
+    hipLaunchKernelGGL(k_update_jobs, dim3(std::min(ntiles, ncu)), dim3(1024), 0, s, f.K, f.ldk, f.dvec, N,
+                       nrows, js, uv, ctr);
+    if (p && !prod) {
+      (void)hipEventRecord(e1, s);
+      p->update_spans.emplace_back(e0, e1);
+      double fl, by;
+      job_work(js, fl, by);
+      p->update_flops.push_back(fl);
+      p->update_bytes.push_back(by);
+    }
+  };
   int buf = 0;
   if (N > 0) {
-    launch_d(0);
+    // a pre-eliminated block: its update of column block 0 first (nothing hides it), that of
+    // column block 1 -- and whatever the plan adds -- beside the first chain
+    if (vdepth > 0) launch_jobs(plan.pre, f.flags + 4 + (LDLT_UPD_COUNTERS - 1));
+    if (vdepth > 0 && lazy && plan.first.njobs > 0) {
+      launch_fused(0, std::min(OB, N), plan.first, f.flags + 4);
+    } else {
+      launch_d(0);
+      if (vdepth > 0) launch_jobs(plan.first, f.flags + 4);
+    }
     launch_t(0, f.W);
   }
   for (int c0 = 0; c0 + OB < N; c0 += OB, buf ^= 1) {
@@ -2090,53 +2208,12 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
     }
     // D(k + 1) beside trailing-update work, in one launch; while profiling (per-kernel events)
     // and on request (PGF_FUSED=0) D(k + 1) and the whole of U(k) as two launches
+    int *ctr = f.flags + 4 + ((c0 / OB + 1) % (LDLT_UPD_COUNTERS - 1));
     if (lazy) {
-      const UpdJobs &js = plan.launch[c0 / OB];
-      const int ntiles = js.tile_begin[js.njobs];
-      const int ep = next_help_epoch();
-      if (prod) {
-        span_begin(pr.fused_spans);
-        double fl, by;
-        job_work(js, fl, by);
-        p->fused_flops.push_back(fl);
-        p->fused_bytes.push_back(by);
-      }
-      int *ctr = f.flags + 4 + ((c0 / OB + 1) % LDLT_UPD_COUNTERS);
-      const int workers = std::min(ntiles, ncu - 3);  // one workgroup per CU: persistent tile loops
-      if (chain3_on())
-        hipLaunchKernelGGL(k_chain3_update, dim3(1 + workers), dim3(1024), 0, s, f.K, f.ldk, c1, nb1,
-                           f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, N, nrows, js, ctr);
-      else if (help)
-        hipLaunchKernelGGL(k_chain_update<true>, dim3(std::max(17, workers + 3)), dim3(1024), 0, s,
-                           f.K, f.ldk, c1, nb1, f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, f.hctl, ep,
-                           N, nrows, js, ctr);
-      else
-        hipLaunchKernelGGL(k_chain_update<false>, dim3(1 + workers), dim3(1024), 0, s, f.K, f.ldk,
-                           c1, nb1, f.dvec, f.dinv, f.flags, f.Linv, f.LinvT, f.hctl, ep, N, nrows,
-                           js, ctr);
-      if (prod) span_end(pr.fused_spans);
+      launch_fused(c1, nb1, plan.launch[c0 / OB], ctr);
     } else {
       launch_d(c1);
-      const UpdJobs &js = plan.launch[c0 / OB];
-      const int ntiles = js.tile_begin[js.njobs];
-      if (ntiles > 0) {
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (p) {
-          e0 = prof_event(p);
-          e1 = prof_event(p);
-          (void)hipEventRecord(e0, s);
-        }
-        hipLaunchKernelGGL(k_update_jobs, dim3(std::min(ntiles, ncu)), dim3(1024), 0, s, f.K, f.ldk,
-                           f.dvec, N, nrows, js, f.flags + 4 + ((c0 / OB + 1) % LDLT_UPD_COUNTERS));
-        if (p) {
-          (void)hipEventRecord(e1, s);
-          p->update_spans.emplace_back(e0, e1);
-          double fl, by;
-          job_work(js, fl, by);
-          p->update_flops.push_back(fl);
-          p->update_bytes.push_back(by);
-        }
-      }
+      launch_jobs(plan.launch[c0 / OB], ctr);
     }
     launch_t(c1, f.W + (size_t)(buf ^ 1) * f.wstride);
   }

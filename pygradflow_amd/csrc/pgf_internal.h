@@ -65,6 +65,16 @@ struct DenseLdlt {
   bool factored = false;
   int n_neg = 0;
   PgfProfile *prof = nullptr;
+  // A pre-eliminated diagonal block (the condensed KKT system, pgf_api.hip): when vdepth > 0 the
+  // matrix to factorise is K - V diag(vd) V^T, V = (N + 1) x vdepth row-major (row N rides along
+  // like row N of K); the look-ahead schedule applies it as `virtual' column blocks that are
+  // already factorised, lazily, like any other pending block.  vneg = its negative pivots.
+  double *V = nullptr;
+  int64_t ldv = 0;
+  double *vd = nullptr;
+  int vdepth = 0;  // multiple of 32 (zero-padded columns)
+  int vneg = 0;
+  size_t vcap = 0, vdcap = 0;  // allocated doubles
   int inject_chain_failure = 0;  // test hook: the next chained solve reports a failure
   int inject_helper_failure = 0;  // test hook: the next factorisation reports failed helpers
 };

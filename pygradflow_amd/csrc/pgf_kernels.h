@@ -58,3 +58,13 @@ void launch_symmetrize(hipStream_t s, double *A, int64_t ld, int N);
 // ||H||_inf, ||J||_inf, ||J||_1 -> norms3 (device), for the normwise backward error of the guard
 void launch_matrix_norms(hipStream_t s, int n, int m, const double *H, int64_t ldh, const double *J,
                          int64_t ldj, double *norms3);
+// condensed KKT system (constraint block eliminated first; pgf_kernels.hip, pgf_api.hip):
+// V <- J[:, I]^T zero-padded to mp columns, row nI <- rhs_y (or 0), vd <- -1 / delta
+void launch_cond_panel(hipStream_t s, double *V, int64_t ldv, int mp, double *vd, const double *J,
+                       int64_t ldj, const int *idxI, int nI, int m, double delta, const double *rhs_y);
+// out <- rhs_x + V rhs_y / delta
+void launch_cond_rhs(hipStream_t s, int nI, int m, const double *V, int64_t ldv, const double *rhs,
+                     double delta, double *out);
+// sol_y <- (V^T sol_x - rhs_y) / delta
+void launch_cond_y(hipStream_t s, int nI, int m, const double *V, int64_t ldv, const double *solx,
+                   const double *rhs_y, double delta, double *partial, int nparts, double *sol_y);

@@ -1310,3 +1310,92 @@ void batch_launch_measures(hipStream_t s, const BInst *tab, int B, const BatchSc
                        nb);
   hipLaunchKernelGGL(kb_measures_final, dim3(1, 1, B), dim3(256), 0, s, red4, nb, out);
 }
+
+// ---------------------------------------------------------------- condensed KKT system
+// With the constraint block -delta I eliminated first (block elimination of
+// [[H[I,I] + lamb I, J_I^T], [J_I, -delta I]], the reference's SymmetricStepSolver matrix,
+// step/solver/symmetric_step_solver.py:35-76) what is factorised is the nI x nI Schur complement
+//     S = H[I,I] + lamb I + J_I^T J_I / delta,
+// applied by the factorisation itself from the panel V = J_I^T (nI x m, row-major, zero-padded to
+// a multiple of 32 columns) with D-scaling vd = -1 / delta (DenseLdlt::V, pgf_factor2.hip).
+// Row nI of V carries the constraint rows of the right-hand side, so that the elimination turns
+// row nI of K (b_x) into b_x + J_I^T b_y / delta on the way.
+//   S s_x = b_x + J_I^T b_y / delta,      s_y = (J_I s_x - b_y) / delta.
+
+// V[i][r] = J[r][idxI[i]] (r < m), 0 for the padding columns: 32 x 32 tiles through LDS, reads
+// run along i (contiguous whenever I is), writes along r
+__global__ __launch_bounds__(256) void k_cond_panel(double *__restrict__ V, int64_t ldv, int mp,
+                                                    const double *__restrict__ J, int64_t ldj,
+                                                    const int *__restrict__ idxI, int nI, int m) {
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int i0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int i = i0 + tx;
+  const int col = i < nI ? idxI[i] : 0;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = r0 + ty + 8 * p;
+    tile[ty + 8 * p][tx] = (r < m && i < nI) ? J[(int64_t)r * ldj + col] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int ii = i0 + ty + 8 * p, r = r0 + tx;
+    if (ii < nI && r < mp) V[(int64_t)ii * ldv + r] = tile[tx][ty + 8 * p];
+  }
+}
+
+// row nI of V <- the constraint part of the right-hand side (or zeros), vd <- -1 / delta
+__global__ void k_cond_tail(double *__restrict__ Vrow, double *__restrict__ vd, int mp, int m,
+                            const double *__restrict__ rhs_y, double delta) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= mp) return;
+  Vrow[r] = (rhs_y && r < m) ? rhs_y[r] : 0.0;
+  vd[r] = -1.0 / delta;
+}
+
+// out[i] = rhs[i] + dot(V[i][0:m], rhs[nI:nI+m]) / delta
+__global__ __launch_bounds__(256) void k_cond_rhs(int nI, int m, const double *__restrict__ V, int64_t ldv,
+                                                  const double *__restrict__ rhs, double delta,
+                                                  double *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= nI) return;
+  const double d = row_dot(V + (int64_t)i * ldv, rhs + nI, m, lane);
+  if (lane == 0) out[i] = rhs[i] + d / delta;
+}
+
+// sol_y[r] = (sum_p partial[p][r] - rhs_y[r]) / delta   (partial: V^T s_x in fixed row chunks)
+__global__ void k_cond_y(int m, int nparts, const double *__restrict__ partial,
+                         const double *__restrict__ rhs_y, double delta, double *__restrict__ sol_y) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= m) return;
+  double s = 0.0;
+  for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * m + r];
+  sol_y[r] = (s - rhs_y[r]) / delta;
+}
+
+void launch_cond_panel(hipStream_t s, double *V, int64_t ldv, int mp, double *vd, const double *J,
+                       int64_t ldj, const int *idxI, int nI, int m, double delta, const double *rhs_y) {
+  if (nI > 0 && mp > 0)
+    hipLaunchKernelGGL(k_cond_panel, dim3((nI + 31) / 32, mp / 32), dim3(256), 0, s, V, ldv, mp, J, ldj,
+                       idxI, nI, m);
+  if (mp > 0)
+    hipLaunchKernelGGL(k_cond_tail, g1(mp), dim3(256), 0, s, V + (int64_t)nI * ldv, vd, mp, m, rhs_y, delta);
+}
+
+void launch_cond_rhs(hipStream_t s, int nI, int m, const double *V, int64_t ldv, const double *rhs,
+                     double delta, double *out) {
+  if (nI) hipLaunchKernelGGL(k_cond_rhs, dim3((nI + 3) / 4), dim3(256), 0, s, nI, m, V, ldv, rhs, delta, out);
+}
+
+void launch_cond_y(hipStream_t s, int nI, int m, const double *V, int64_t ldv, const double *solx,
+                   const double *rhs_y, double delta, double *partial, int nparts, double *sol_y) {
+  if (!m) return;
+  const int chunk = (std::max(nI, 1) + nparts - 1) / nparts;
+  const int used = nI > 0 ? (nI + chunk - 1) / chunk : 0;
+  if (used)
+    hipLaunchKernelGGL(k_gemvT_partial, dim3((m + 255) / 256, used), dim3(256), 0, s, nI, m, V, ldv, solx,
+                       chunk, partial);
+  hipLaunchKernelGGL(k_cond_y, g1(m), dim3(256), 0, s, m, used, partial, rhs_y, delta, sol_y);
+}

@@ -1372,6 +1372,8 @@ void ldlt_free(DenseLdlt &f) {
   if (f.chain) (void)hipFree(f.chain);
   if (f.xpub) (void)hipFree(f.xpub);
   if (f.hctl) (void)hipFree(f.hctl);
+  if (f.V) (void)hipFree(f.V);
+  if (f.vd) (void)hipFree(f.vd);
   if (f.h_flags) (void)hipHostFree(f.h_flags);
   f = DenseLdlt();
 }
@@ -1488,7 +1490,7 @@ int ldlt_finish(DenseLdlt &f, hipError_t *err) {
     f.factored = false;
     return 2;
   }
-  f.n_neg = f.h_flags[1];
+  f.n_neg = f.h_flags[1] + (f.vdepth > 0 ? f.vneg : 0);
   f.factored = (f.h_flags[0] == 0);
   return f.h_flags[0] ? 1 : 0;
 }

@@ -146,7 +146,10 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int tid, 
       const int p = q * NT + tid;
       const int row = p / PPR, kofs = (p % PPR) * 2;
       const int gj = min(j0 + row, colEnd - 1);
-      pb[q] = ld_f64x2(K + (int64_t)gj * ldk + kc0 + kk + kofs, coh);
+      // (SCALE: both operands are rows of the same panel W -- K + kc0 for an ordinary block, the
+      // pre-eliminated block's panel V for a virtual one, pgf_factor2.hip)
+      pb[q] = SCALE ? ld_f64x2(W + (int64_t)gj * ldw + kk + kofs, coh)
+                    : ld_f64x2(K + (int64_t)gj * ldk + kc0 + kk + kofs, coh);
     }
   };
   auto stage = [&](int buf, int = 0) {

@@ -308,6 +308,14 @@ class DeviceNewton:
                    self._hd.h, "pgf_qp_measures")
         return dict(stat_res=out[0], cons_violation=out[1], bound_violation=out[2], y_inf=out[3])
 
+    def refinement_stats(self):
+        """(refinement steps, LU fallbacks, relative residual of the last checked solve) of the
+        residual guard (``pgf_refinement_stats``)."""
+        a, b, r = C.c_int(0), C.c_int(0), C.c_double(0.0)
+        _lib.check(self._lib.pgf_refinement_stats(self._hd.h, C.byref(a), C.byref(b), C.byref(r)),
+                   self._hd.h)
+        return a.value, b.value, r.value
+
     def profile(self, on=True):
         """on = True / 1: the factorisation's kernels as separate launches with a HIP-event span
         each (per-kernel figures); 2: spans around the PRODUCTION launches (``fused_*``:
