@@ -337,6 +337,11 @@ int pgf_debug_fail_next_helper(pgf_handle h);
  * reject and repeat, and the helpers are switched off */
 int pgf_batch_debug_fail_next_helper(pgf_batch b);
 int pgf_debug_chain_helpers(int on);
+/* Which factorisation the handle's current dense factor is (tests, tools/check_condensed.py):
+ * 0 none / stale, 1 LDL^T of the reduced KKT matrix in its natural order, 2 LDL^T of the
+ * condensed system (constraint block eliminated first, pgf_api.hip condensed_wanted), 3 the
+ * pivoted LU that took over after a failed residual check. */
+int pgf_debug_factor_kind(pgf_handle h);
 
 #ifdef __cplusplus
 }

@@ -557,8 +557,8 @@ static hipError_t kkt_solve_async(pgf_handle h, const double *rhs, double *sol) 
   launch_cond_rhs(h->stream, h->nI, h->m, f.V, f.ldv, rhs, h->delta, h->cd_t);
   hipError_t e = ldlt_solve_async(f, h->cd_t, sol);
   if (e != hipSuccess) return e;
-  launch_cond_y(h->stream, h->nI, h->m, f.V, f.ldv, sol, rhs + h->nI, h->delta, h->partial, PGF_GEMVT_PARTS,
-                sol + h->nI);
+  launch_cond_y(h->stream, h->nI, h->m, f.V, f.ldv, sol, rhs + h->nI, h->delta, h->partial,
+                (size_t)PGF_GEMVT_PARTS * (h->n ? h->n : 1), sol + h->nI);
   return hipGetLastError();
 }
 // the backward half for the right-hand side h->rhs that rode through the factorisation
@@ -568,7 +568,7 @@ static hipError_t kkt_backsolve_async(pgf_handle h, double *sol) {
   hipError_t e = ldlt_backsolve_async(f, f.K + (int64_t)h->nI * f.ldk, sol);
   if (e != hipSuccess) return e;
   launch_cond_y(h->stream, h->nI, h->m, f.V, f.ldv, sol, h->rhs + h->nI, h->delta, h->partial,
-                PGF_GEMVT_PARTS, sol + h->nI);
+                (size_t)PGF_GEMVT_PARTS * (h->n ? h->n : 1), sol + h->nI);
   return hipGetLastError();
 }
 
@@ -1503,6 +1503,13 @@ int pgf_debug_fail_next_helper(pgf_handle h) {
   if (!h) return PGF_INVALID;
   h->fac.inject_helper_failure = 1;
   return PGF_OK;
+}
+
+int pgf_debug_factor_kind(pgf_handle h) {
+  if (!h || h->sparse) return 0;
+  if (h->lu_active) return 3;
+  if (!h->fac.factored) return 0;
+  return h->condensed ? 2 : 1;
 }
 
 int pgf_debug_chain_helpers(int on) {

@@ -1518,10 +1518,12 @@ struct UpdJobs {
   int col0[UPD_MAXJOBS], rowstart[UPD_MAXJOBS], kc0[UPD_MAXJOBS], KB[UPD_MAXJOBS];
   int ntc[UPD_MAXJOBS];  // 128-wide tile columns of the job (2 per column block; adjacent column
                          // blocks with the same K-range share a job: large N, eager plan)
-  unsigned char virt[UPD_MAXJOBS];  // the K-range lies in the pre-eliminated block's panel (UpdVirt)
+  // a leading segment of the K-range in the pre-eliminated block's panel (UpdVirt): columns
+  // [kc0v, kc0v + KBv) of V first, then columns [kc0, kc0 + KB) of K (either may be empty) -- ONE
+  // job, one pass over the tiles: two jobs on the same tiles of a launch would race
+  int kc0v[UPD_MAXJOBS], KBv[UPD_MAXJOBS];
 };
-// The pre-eliminated block (DenseLdlt::V): panel rows V[i][.], D-scaling vd -- a job with virt set
-// reads both operands from it instead of from columns [kc0, kc0 + KB) of K.
+// The pre-eliminated block (DenseLdlt::V): panel rows V[i][.], D-scaling vd.
 struct UpdVirt {
   const double *V;
   int64_t ldv;
@@ -1549,13 +1551,14 @@ __device__ __forceinline__ void update_job_tile(unsigned char *smem, int t, doub
     t -= nc;
   }
   i0 += UPD_TM * t;
-  const int kc0 = jobs.kc0[q];
-  const bool vj = jobs.virt[q] != 0;
-  const double *Wp = vj ? uv.V + kc0 : K + kc0;
-  const int64_t ldw = vj ? uv.ldv : ldk;
-  const double *ds = vj ? uv.vd + kc0 : dvec + kc0;
-  update_tile<UPD_TM, 128, 32, 4, 4, 1, true>(smem, threadIdx.x, i0, j0, K, ldk, Wp, ldw, N, nrows, N, kc0,
-                                              jobs.KB[q], ds);
+  const int kc0 = jobs.kc0[q], KBr = jobs.KB[q], kc0v = jobs.kc0v[q], KBv = jobs.KBv[q];
+  if (KBv > 0)
+    update_tile<UPD_TM, 128, 32, 4, 4, 1, true>(smem, threadIdx.x, i0, j0, K, ldk, uv.V + kc0v, uv.ldv, N,
+                                                nrows, N, kc0, KBv + KBr, uv.vd + kc0v, KBv, K + kc0, ldk,
+                                                dvec + kc0);
+  else
+    update_tile<UPD_TM, 128, 32, 4, 4, 1, true>(smem, threadIdx.x, i0, j0, K, ldk, K + kc0, ldk, N, nrows, N,
+                                                kc0, KBr, dvec + kc0);
 }
 
 // The update role, persistent: a workgroup takes tile after tile of the launch's job table from an
@@ -1610,6 +1613,65 @@ __global__ __launch_bounds__(1024) void k_update_jobs(double *K, int64_t ldk,
                                                       int *ctr) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 256 * 34 * 8];
   update_worker(smem, K, ldk, dvec, N, nrows, jobs, uv, ctr);
+}
+
+// The pre-eliminated block's update of ONE diagonal block, C -= V diag(vd) V^T on rows and columns
+// [c0, c0 + nb): the only piece of it the first chain waits for.  Latency, not throughput (a
+// 128 x 128 job tile of depth 1024 would take ~85 us): one 16 x 16 tile of the lower triangle per
+// workgroup, its four wavefronts taking the 16-column chunks of the depth in turn (c = w, w + 4,
+// ...; two chunks in flight per wavefront: the operands come straight from L2, ~1 us per dependent
+// round trip) and summed through LDS in a fixed order.  Lane (l15, l4) reads four consecutive
+// doubles of its row per chunk and feeds component t to MFMA t: the sum over k does not care
+// which lane group carries which k as long as A and B agree.
+__global__ __launch_bounds__(256) void k_virtual_diag(double *K, int64_t ldk, int c0, int nb,
+                                                      const double *__restrict__ V, int64_t ldv,
+                                                      const double *__restrict__ vd, int depth, int vrows) {
+  __shared__ double part[4][4][64];
+  int ti = 0;
+  const int t = (int)blockIdx.x;
+  while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+  const int tj = t - ti * (ti + 1) / 2;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int i0 = 16 * ti, j0 = 16 * tj;
+  const double *pa = V + (int64_t)min(c0 + i0 + l15, vrows - 1) * ldv + 4 * l4;
+  const double *pb = V + (int64_t)min(c0 + j0 + l15, vrows - 1) * ldv + 4 * l4;
+  const double *pd = vd + 4 * l4;
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  const int nc = depth / 16;
+  for (int c = wave; c < nc; c += 8) {
+    const int k0 = 16 * c;
+    const bool two = c + 4 < nc;
+    const int k1 = two ? k0 + 64 : k0;
+    const double2_t a0 = *reinterpret_cast<const double2_t *>(pa + k0), a1 = *reinterpret_cast<const double2_t *>(pa + k0 + 2);
+    const double2_t b0 = *reinterpret_cast<const double2_t *>(pb + k0), b1 = *reinterpret_cast<const double2_t *>(pb + k0 + 2);
+    const double2_t d0 = *reinterpret_cast<const double2_t *>(pd + k0), d1 = *reinterpret_cast<const double2_t *>(pd + k0 + 2);
+    const double2_t e0 = *reinterpret_cast<const double2_t *>(pa + k1), e1 = *reinterpret_cast<const double2_t *>(pa + k1 + 2);
+    const double2_t f0 = *reinterpret_cast<const double2_t *>(pb + k1), f1 = *reinterpret_cast<const double2_t *>(pb + k1 + 2);
+    const double2_t g0 = *reinterpret_cast<const double2_t *>(pd + k1), g1 = *reinterpret_cast<const double2_t *>(pd + k1 + 2);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0[0] * d0[0], b0[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0[1] * d0[1], b0[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1[0] * d1[0], b1[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1[1] * d1[1], b1[1], acc, 0, 0, 0);
+    if (two) {
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-e0[0] * g0[0], f0[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-e0[1] * g0[1], f0[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-e1[0] * g1[0], f1[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-e1[1] * g1[1], f1[1], acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc[r];
+  __syncthreads();
+  if (wave != 0) return;
+  const int j = j0 + l15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = i0 + l4 + 4 * r;
+    if (i < nb && j <= i) {
+      double *p = K + (int64_t)(c0 + i) * ldk + c0 + j;
+      *p = *p + (((part[0][r][lane] + part[1][r][lane]) + part[2][r][lane]) + part[3][r][lane]);
+    }
+  }
 }
 
 // ------------------------------------------------------------------ batched wrappers
@@ -1859,7 +1921,6 @@ void ldlt_chain_timing_dump() {
 // does.  The budget is therefore chosen per factorisation: the candidate with the smallest
 // estimated total time (plan_cost) -- the reduced size changes from step to step.
 struct UpdPlan {
-  UpdJobs pre;                  // before the first chain (virtual blocks only; no chain beside it)
   UpdJobs first;                // beside the chain of column block 0 (virtual blocks only)
   std::vector<UpdJobs> launch;  // [L - 1]: beside the chain of column block k + 1
   double cost = 0.0;            // estimated sum of launch times in units of one tile-block
@@ -1869,16 +1930,17 @@ struct UpdPlan {
 // blocks that are factorised before the first one: block indices below are unified, virtual blocks
 // [0, nv) first, real block k at nv + k.  Updates commute, so the only deadlines are the usual
 // ones -- a column block's diagonal tile complete before its chain, its rows below before its T --
-// and the virtual blocks are pending work like any other: column block 0 is due before the first
-// chain (stage `pre', the only exposed part), column block 1 beside it (`first'), the rest lazily.
+// and the virtual blocks are pending work like any other: only the first diagonal block is due
+// before the first chain (k_virtual_diag: small tiles, a few microseconds, the only exposed part);
+// the rows below it and column block 1 follow beside that chain (stage `first'), the rest lazily.
 static void plan_updates(UpdPlan &pl, int N, int nrows, int OB, int budget, int cap, double chain_units,
                          int vdepth = 0) {
   const int nblk = (N + OB - 1) / OB;
   const int nv = (vdepth + OB - 1) / OB;
   std::vector<int> done(nblk + 2, 0);
   pl.launch.assign(std::max(0, nblk - 1), UpdJobs());
-  pl.pre.njobs = pl.first.njobs = 0;
-  pl.pre.tile_begin[0] = pl.first.tile_begin[0] = 0;
+  pl.first.njobs = 0;
+  pl.first.tile_begin[0] = 0;
   pl.cost = 0.0;
   auto tiles = [&](int col0, int rowstart) {
     int n = 0;
@@ -1890,23 +1952,37 @@ static void plan_updates(UpdPlan &pl, int N, int nrows, int OB, int budget, int 
     }
     return n;
   };
-  // stage -2: pre, -1: first, k >= 0: the launch beside the chain of column block k + 1
-  for (int st = (nv > 0 ? -2 : 0); st < nblk - 1; ++st) {
+  // stage -1: first, k >= 0: the launch beside the chain of column block k + 1
+  for (int st = (nv > 0 ? -1 : 0); st < nblk - 1; ++st) {
     const int k = st;
     const int avail = st < 0 ? nv - 1 : nv + k;  // newest block whose panel exists
     UpdJobs jb;
     jb.njobs = 0;
     int units = 0, maxdepth = 0, cnt[UPD_MAXJOBS];
-    auto add1 = [&](int J, int rowstart, bool vj, int kc0, int KB, int depth) {
+    // unified blocks [p0, p1]: the virtual part and the real part are the two segments of one job
+    auto add = [&](int J, int rowstart, int p0, int p1) {
+      if (p1 < p0) return;
+      int kc0v = 0, KBv = 0, kc0 = 0, KB = 0;
+      if (p0 < nv) {
+        const int v1 = std::min(p1, nv - 1);
+        kc0v = p0 * OB;
+        KBv = std::min((v1 + 1) * OB, vdepth) - p0 * OB;
+      }
+      if (p1 >= nv) {
+        const int r0 = std::max(p0, nv) - nv, r1 = p1 - nv;
+        kc0 = r0 * OB;
+        KB = (r1 - r0 + 1) * OB;
+      }
+      const int depth = p1 - p0 + 1;
       const int n = tiles(J * OB, rowstart);
-      if (!n || KB <= 0) return;
+      if (!n || KB + KBv <= 0) return;
       units += n * depth;
       maxdepth = std::max(maxdepth, depth);
       // a whole column block right behind the previous job's, same K-range: one job
       if (jb.njobs > 0 && rowstart == J * OB) {
         const int q = jb.njobs - 1;
         if (jb.rowstart[q] == jb.col0[q] && jb.col0[q] + 128 * jb.ntc[q] == J * OB && jb.kc0[q] == kc0 &&
-            jb.KB[q] == KB && (jb.virt[q] != 0) == vj) {
+            jb.KB[q] == KB && jb.kc0v[q] == kc0v && jb.KBv[q] == KBv) {
           jb.ntc[q] += OB / 128;
           cnt[q] += n;
           return;
@@ -1917,31 +1993,16 @@ static void plan_updates(UpdPlan &pl, int N, int nrows, int OB, int budget, int 
       jb.rowstart[q] = rowstart;
       jb.kc0[q] = kc0;
       jb.KB[q] = KB;
+      jb.kc0v[q] = kc0v;
+      jb.KBv[q] = KBv;
       jb.ntc[q] = OB / 128;
-      jb.virt[q] = vj ? 1 : 0;
       cnt[q] = n;
     };
-    // unified blocks [p0, p1]: the virtual part and the real part are separate jobs
-    auto add = [&](int J, int rowstart, int p0, int p1) {
-      if (p1 < p0) return;
-      if (p0 < nv) {
-        const int v1 = std::min(p1, nv - 1);
-        add1(J, rowstart, true, p0 * OB, std::min((v1 + 1) * OB, vdepth) - p0 * OB, v1 - p0 + 1);
-      }
-      if (p1 >= nv) {
-        const int r0 = std::max(p0, nv) - nv, r1 = p1 - nv;
-        add1(J, rowstart, false, r0 * OB, (r1 - r0 + 1) * OB, r1 - r0 + 1);
-      }
-    };
     int Jopt;  // first column block whose pending work is optional at this stage
-    int lim = budget;
-    if (st == -2) {
-      add(0, 0, done[0], avail);
+    const int lim = budget;
+    if (st == -1) {
+      add(0, std::min(OB, N), done[0], avail);  // (its diagonal block: k_virtual_diag)
       done[0] = avail + 1;
-      Jopt = 1;
-      lim = std::max(units, 250 * maxdepth);  // nothing to hide behind: fill the round the tiles of
-                                              // column block 0 occupy anyway, no more
-    } else if (st == -1) {
       if (nblk > 1) {
         add(1, OB, done[1], avail);
         done[1] = avail + 1;
@@ -1961,7 +2022,7 @@ static void plan_updates(UpdPlan &pl, int N, int nrows, int OB, int budget, int 
       const int pend = avail + 1 - done[J];
       if (pend <= 0) continue;
       // (room is kept for the jobs that must run; what is skipped here stays pending)
-      if (units >= lim || jb.njobs >= UPD_MAXJOBS - 4) break;
+      if (units >= lim || jb.njobs >= UPD_MAXJOBS - 2) break;
       const int take = std::min(pend, cap);
       add(J, J * OB, done[J], done[J] + take - 1);
       done[J] += take;
@@ -1969,8 +2030,9 @@ static void plan_updates(UpdPlan &pl, int N, int nrows, int OB, int budget, int 
     // deepest jobs first: their tiles take longest
     int order[UPD_MAXJOBS];
     for (int q = 0; q < jb.njobs; ++q) order[q] = q;
-    std::stable_sort(order, order + jb.njobs, [&](int a, int b) { return jb.KB[a] > jb.KB[b]; });
-    UpdJobs &js = st == -2 ? pl.pre : st == -1 ? pl.first : pl.launch[k];
+    std::stable_sort(order, order + jb.njobs,
+                     [&](int a, int b) { return jb.KB[a] + jb.KBv[a] > jb.KB[b] + jb.KBv[b]; });
+    UpdJobs &js = st == -1 ? pl.first : pl.launch[k];
     js.njobs = jb.njobs;
     js.tile_begin[0] = 0;
     for (int q = 0; q < jb.njobs; ++q) {
@@ -1980,13 +2042,14 @@ static void plan_updates(UpdPlan &pl, int N, int nrows, int OB, int budget, int 
       js.kc0[q] = jb.kc0[o];
       js.KB[q] = jb.KB[o];
       js.ntc[q] = jb.ntc[o];
-      js.virt[q] = jb.virt[o];
+      js.kc0v[q] = jb.kc0v[o];
+      js.KBv[q] = jb.KBv[o];
       js.tile_begin[q + 1] = js.tile_begin[q] + cnt[o];
     }
     // list-scheduling estimate of the launch: work / 253 CUs, at least the deepest tile, in
-    // whole tile times; and never less than the chain (stage `pre' has none)
+    // whole tile times; and never less than the chain
     const double t = std::max((double)maxdepth, std::ceil(units / 253.0));
-    pl.cost += st == -2 ? t : std::max(chain_units, t);
+    pl.cost += std::max(chain_units, t);
   }
 }
 
@@ -2135,8 +2198,9 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
       const int rs = std::max(js.rowstart[q], col0);
       double cnt = 0.0;
       for (int i = rs; i < nrows; ++i) cnt += std::min(colEnd, i + 1) - col0;
-      fl += 2.0 * cnt * js.KB[q];
-      by += 16.0 * cnt + 8.0 * js.KB[q] * ((double)(nrows - rs) + (double)(colEnd - col0));
+      const double kd = js.KB[q] + js.KBv[q];
+      fl += 2.0 * cnt * kd;
+      by += 16.0 * cnt + 8.0 * kd * ((double)(nrows - rs) + (double)(colEnd - col0));
     }
   };
   // chain of column block [c1, c1 + nb1) beside the update jobs js, one launch
@@ -2185,9 +2249,13 @@ hipError_t ldlt_factor2_async(DenseLdlt &f, int N, int nrows) {
   };
   int buf = 0;
   if (N > 0) {
-    // a pre-eliminated block: its update of column block 0 first (nothing hides it), that of
-    // column block 1 -- and whatever the plan adds -- beside the first chain
-    if (vdepth > 0) launch_jobs(plan.pre, f.flags + 4 + (LDLT_UPD_COUNTERS - 1));
+    // a pre-eliminated block: its update of the first diagonal block first (nothing hides it), the
+    // rest of column block 0, column block 1 -- and whatever the plan adds -- beside the first chain
+    if (vdepth > 0) {
+      const int nb0 = std::min(OB, N), nt = (nb0 + 15) / 16;
+      hipLaunchKernelGGL(k_virtual_diag, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, f.K, f.ldk, 0, nb0, f.V,
+                         f.ldv, f.vd, vdepth, nrows);
+    }
     if (vdepth > 0 && lazy && plan.first.njobs > 0) {
       launch_fused(0, std::min(OB, N), plan.first, f.flags + 4);
     } else {

@@ -67,4 +67,4 @@ void launch_cond_rhs(hipStream_t s, int nI, int m, const double *V, int64_t ldv,
                      double delta, double *out);
 // sol_y <- (V^T sol_x - rhs_y) / delta
 void launch_cond_y(hipStream_t s, int nI, int m, const double *V, int64_t ldv, const double *solx,
-                   const double *rhs_y, double delta, double *partial, int nparts, double *sol_y);
+                   const double *rhs_y, double delta, double *partial, size_t partial_cap, double *sol_y);

@@ -1365,14 +1365,21 @@ __global__ __launch_bounds__(256) void k_cond_rhs(int nI, int m, const double *_
   if (lane == 0) out[i] = rhs[i] + d / delta;
 }
 
-// sol_y[r] = (sum_p partial[p][r] - rhs_y[r]) / delta   (partial: V^T s_x in fixed row chunks)
-__global__ void k_cond_y(int m, int nparts, const double *__restrict__ partial,
-                         const double *__restrict__ rhs_y, double delta, double *__restrict__ sol_y) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= m) return;
+// sol_y[r] = (sum_p partial[p][r] - rhs_y[r]) / delta   (partial: V^T s_x in fixed row chunks);
+// 64 columns per workgroup, four groups of lanes take the chunks p = g, g + 4, ... and are summed
+// in a fixed order
+__global__ __launch_bounds__(256) void k_cond_y(int m, int nparts, const double *__restrict__ partial,
+                                                const double *__restrict__ rhs_y, double delta,
+                                                double *__restrict__ sol_y) {
+  __shared__ double part[4][64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int r = blockIdx.x * 64 + c;
   double s = 0.0;
-  for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * m + r];
-  sol_y[r] = (s - rhs_y[r]) / delta;
+  if (r < m)
+    for (int p = g; p < nparts; p += 4) s += partial[(int64_t)p * m + r];
+  part[g][c] = s;
+  __syncthreads();
+  if (g == 0 && r < m) sol_y[r] = (((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) - rhs_y[r]) / delta;
 }
 
 void launch_cond_panel(hipStream_t s, double *V, int64_t ldv, int mp, double *vd, const double *J,
@@ -1390,12 +1397,14 @@ void launch_cond_rhs(hipStream_t s, int nI, int m, const double *V, int64_t ldv,
 }
 
 void launch_cond_y(hipStream_t s, int nI, int m, const double *V, int64_t ldv, const double *solx,
-                   const double *rhs_y, double delta, double *partial, int nparts, double *sol_y) {
+                   const double *rhs_y, double delta, double *partial, size_t partial_cap, double *sol_y) {
   if (!m) return;
+  // as many row chunks as the scratch holds (up to 128): the product reads V once, 8 m nI bytes
+  const int nparts = (int)std::max<size_t>(1, std::min<size_t>(128, partial_cap / (size_t)m));
   const int chunk = (std::max(nI, 1) + nparts - 1) / nparts;
   const int used = nI > 0 ? (nI + chunk - 1) / chunk : 0;
   if (used)
     hipLaunchKernelGGL(k_gemvT_partial, dim3((m + 255) / 256, used), dim3(256), 0, s, nI, m, V, ldv, solx,
                        chunk, partial);
-  hipLaunchKernelGGL(k_cond_y, g1(m), dim3(256), 0, s, m, used, partial, rhs_y, delta, sol_y);
+  hipLaunchKernelGGL(k_cond_y, dim3((m + 63) / 64), dim3(256), 0, s, m, used, partial, rhs_y, delta, sol_y);
 }

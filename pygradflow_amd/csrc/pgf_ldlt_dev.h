@@ -87,7 +87,9 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int tid, 
                                             double *__restrict__ K, int64_t ldk,
                                             const double *__restrict__ W, int64_t ldw, int N,
                                             int nrows, int colEnd, int kc0, int KBc,
-                                            const double *__restrict__ dsc = nullptr) {
+                                            const double *__restrict__ dsc = nullptr,
+                                            int KB1 = 1 << 30, const double *__restrict__ W2 = nullptr,
+                                            int64_t ldw2 = 0, const double *__restrict__ dsc2 = nullptr) {
   const int KB = KBc;  // K-depth
   const int coh = 0;
   constexpr int NT = 64 * WR * WC;           // threads per workgroup
@@ -128,8 +130,22 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int tid, 
   static_assert(!SCALE || NT % PPR == 0, "one D pair per thread");
   double2_t pa[PA], pb[PB], pd = (double2_t){1.0, 1.0};
   bool staged_once = false;
+  // SCALE: the K-range may consist of two segments -- chunks [0, KB1) from the panel (W, ldw, dsc),
+  // chunks [KB1, KB) from (W2, ldw2, dsc2): a pre-eliminated block's panel V followed by columns
+  // of K (pgf_factor2.hip; two jobs on the same tiles in one launch would race).  KB1 is a
+  // multiple of BK; the choice is uniform over the workgroup.
   auto fetch = [&](int kk, int = 0) {
     if ((EXP & 1) && kk > 0) return;
+    const double *__restrict__ Wc = W;
+    const double *__restrict__ dc = dsc;
+    int64_t ldc = ldw;
+    int kq = kk;
+    if (SCALE && kk >= KB1) {
+      Wc = W2;
+      dc = dsc2;
+      ldc = ldw2;
+      kq = kk - KB1;
+    }
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
       const int p = q * NT + tid;
@@ -138,17 +154,17 @@ __device__ __forceinline__ void update_tile(unsigned char *smem, const int tid, 
       // accumulator rows that are never stored, and a predicated load costs the prefetch a
       // branch with a full s_waitcnt at its join
       const int gi = min(i0 + row, nrows - 1);
-      pa[q] = ld_f64x2(W + (int64_t)gi * ldw + kk + kofs, coh);
+      pa[q] = ld_f64x2(Wc + (int64_t)gi * ldc + kq + kofs, coh);
     }
-    if (SCALE) pd = *reinterpret_cast<const double2_t *>(dsc + kk + (tid % PPR) * 2);
+    if (SCALE) pd = *reinterpret_cast<const double2_t *>(dc + kq + (tid % PPR) * 2);
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
       const int p = q * NT + tid;
       const int row = p / PPR, kofs = (p % PPR) * 2;
       const int gj = min(j0 + row, colEnd - 1);
-      // (SCALE: both operands are rows of the same panel W -- K + kc0 for an ordinary block, the
-      // pre-eliminated block's panel V for a virtual one, pgf_factor2.hip)
-      pb[q] = SCALE ? ld_f64x2(W + (int64_t)gj * ldw + kk + kofs, coh)
+      // (SCALE: both operands are rows of the same panel -- K + kc0 for an ordinary block, the
+      // pre-eliminated block's panel V for a virtual one)
+      pb[q] = SCALE ? ld_f64x2(Wc + (int64_t)gj * ldc + kq + kofs, coh)
                     : ld_f64x2(K + (int64_t)gj * ldk + kc0 + kk + kofs, coh);
     }
   };

@@ -308,6 +308,11 @@ class DeviceNewton:
                    self._hd.h, "pgf_qp_measures")
         return dict(stat_res=out[0], cons_violation=out[1], bound_violation=out[2], y_inf=out[3])
 
+    def factor_kind(self):
+        """0 none, 1 LDL^T in the natural order, 2 LDL^T of the condensed system, 3 pivoted LU
+        (``pgf_debug_factor_kind``)."""
+        return int(self._lib.pgf_debug_factor_kind(self._hd.h))
+
     def refinement_stats(self):
         """(refinement steps, LU fallbacks, relative residual of the last checked solve) of the
         residual guard (``pgf_refinement_stats``)."""

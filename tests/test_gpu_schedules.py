@@ -71,6 +71,32 @@ def test_batched_schedule_variant_matches_one_by_one(gpu_available, name):
     assert "batch ok" in out.stdout
 
 
+CONDENSED_VARIANTS = {
+    "condensed_forced": {"PGF_CONDENSED": "2"},     # constraint block eliminated first at every size
+    "natural_order": {"PGF_CONDENSED": "0"},        # the reduced KKT matrix as it stands
+    "condensed_unfused": {"PGF_CONDENSED": "2", "PGF_FUSED": "0"},
+    "condensed_tight_budget": {"PGF_CONDENSED": "2", "PGF_LAZY_BUDGET": "40", "PGF_LAZY_CAP": "1"},
+    "condensed_no_helpers": {"PGF_CONDENSED": "2", "PGF_CHAIN_HELP": "0"},
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CONDENSED_VARIANTS))
+def test_condensed_factorisation_matches_oracle(gpu_available, name):
+    """tools/check_condensed.py: Full / Simplified / ActiveSet steps on boxed dense QPs whose
+    constraint block spans zero to three 256-column blocks (ragged), against the CPU oracle, with
+    the pivot order the variant asks for (checked through pgf_debug_factor_kind), no refinement and
+    inertia m."""
+    if not gpu_available:
+        pytest.skip("needs a GPU")
+    env = dict(os.environ)
+    env.update(CONDENSED_VARIANTS[name])
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "check_condensed.py")], env=env,
+                         cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "condensed ok" in out.stdout
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(VARIANTS))
 def test_schedule_variant_factorises_correctly(gpu_available, name):
