@@ -42,10 +42,15 @@ if __name__ == "__main__":
     if len(sys.argv) > 3:
         rec = {}
         for k in out:
-            if "ldlt_update" not in k and "k_update_jobs" not in k:
+            if "ldlt_update" not in k and "k_update_jobs" not in k and "chain_update" not in k:
                 continue
-            key = ("kb_ldlt_update" if k.startswith("kb_") else
+            key = ("kb_chain_update" if "kb_chain_update" in k else
+                   "k_chain_update" if "k_chain_update" in k else
+                   "kb_ldlt_update" if k.startswith("kb_") else
                    "k_update_jobs" if "k_update_jobs" in k else "k_ldlt_update")
+            if key in rec:  # (template instances of one kernel: keep the one with more launches)
+                if rec[key]["launches"] >= out[k]["launches"]:
+                    continue
             rec[key] = dict(out[k], kernel=k,
                             note="(2*FETCH_SIZE + WRITE_SIZE) KiB averaged over all launches; "
                                  "gfx950 FETCH_SIZE x2 correction; estimate")
