@@ -197,8 +197,13 @@ __global__ __launch_bounds__(256) void kb_update_diag(const BInst *__restrict__ 
 // POST (k_trsm_ud): after the stores of sub-panel s have reached L2 the workgroup posts
 // post[s] = postval -- the update of the next diagonal block runs in the same launch and takes
 // the rows sub-panel by sub-panel.
-template <bool POST = false>
-__device__ __forceinline__ void trsm_block_body(double (*Xs)[16][C_LD], double *ds, int wg, double *K,
+// RT: 16-row tiles per workgroup.  1 where the launch is bound by the latency of one row group
+// (single instance: ~250 row groups, one per CU); the batched launches -- thousands of row
+// groups, three resident per CU, each pulling its own copy of the B slices through the CU's
+// texture path -- take 2: every B register feeds two MFMAs (kb_trsm_block, 32 instances:
+// 100 -> ... us).
+template <bool POST = false, int RT = 1>
+__device__ __forceinline__ void trsm_block_body(double (*Xs)[16 * RT][C_LD], double *ds, int wg, double *K,
                                                 int64_t ldk, double *W, int64_t ldw, int nrows,
                                                 int c0, int nb, const double *__restrict__ dinv,
                                                 const double *__restrict__ Linv, int *post = nullptr,
@@ -206,7 +211,7 @@ __device__ __forceinline__ void trsm_block_body(double (*Xs)[16][C_LD], double *
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int bend = c0 + nb;
-  const int r0 = bend + 16 * wg;
+  const int r0 = bend + 16 * RT * wg;
   const int ns = (nb + 63) / 64;
   constexpr int DEPTH = 3;
   double2_t bq[DEPTH][8];
@@ -226,16 +231,18 @@ __device__ __forceinline__ void trsm_block_body(double (*Xs)[16][C_LD], double *
   };
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) fetch_b(bq[d], d);
-  double4_t acc[4];
+  double4_t acc[RT][4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int j = c0 + 64 * s + 16 * wc + l15;
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = r0 + l4 + 4 * r;
-      acc[s][r] = (i < nrows && j < bend) ? K[(int64_t)i * ldk + j] : 0.0;
+    for (int s = 0; s < 4; ++s) {
+      const int j = c0 + 64 * s + 16 * wc + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = r0 + 16 * rt + l4 + 4 * r;
+        acc[rt][s][r] = (i < nrows && j < bend) ? K[(int64_t)i * ldk + j] : 0.0;
+      }
     }
-  }
   ds[tid] = (tid < nb) ? dinv[c0 + tid] : 0.0;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -245,16 +252,20 @@ __device__ __forceinline__ void trsm_block_body(double (*Xs)[16][C_LD], double *
 #pragma unroll
       for (int t = 0; t < s; ++t) {
         const int idx = s * (s + 1) / 2 + t;  // compile-time after unrolling
-        double4_t a4 = acc[s];
-        double2_t av[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) av[j] = *reinterpret_cast<const double2_t *>(&Xs[t][l15][8 * j + 2 * l4]);
+        for (int rt = 0; rt < RT; ++rt) {
+          double4_t a4 = acc[rt][s];
+          double2_t av[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[j].x, bq[idx % DEPTH][j].x, a4, 0, 0, 0);
-          a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[j].y, bq[idx % DEPTH][j].y, a4, 0, 0, 0);
+          for (int j = 0; j < 8; ++j)
+            av[j] = *reinterpret_cast<const double2_t *>(&Xs[t][16 * rt + l15][8 * j + 2 * l4]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[j].x, bq[idx % DEPTH][j].x, a4, 0, 0, 0);
+            a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[j].y, bq[idx % DEPTH][j].y, a4, 0, 0, 0);
+          }
+          acc[rt][s] = a4;
         }
-        acc[s] = a4;
         fetch_b(bq[idx % DEPTH], idx + DEPTH);  // the slot just emptied
       }
       {
@@ -263,23 +274,32 @@ __device__ __forceinline__ void trsm_block_body(double (*Xs)[16][C_LD], double *
         const int idx = s * (s + 1) / 2 + s;
         double(*St)[C_LD] = Xs[s];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) St[l4 + 4 * r][16 * wc + l15] = acc[s][r];
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) St[16 * rt + l4 + 4 * r][16 * wc + l15] = acc[rt][s][r];
         __syncthreads();
-        double4_t x = (double4_t){0.0, 0.0, 0.0, 0.0};
-        double2_t av[8];
+        double4_t x[RT];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) av[j] = *reinterpret_cast<const double2_t *>(&St[l15][8 * j + 2 * l4]);
+        for (int rt = 0; rt < RT; ++rt) {
+          x[rt] = (double4_t){0.0, 0.0, 0.0, 0.0};
+          double2_t av[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j].x, bq[idx % DEPTH][j].x, x, 0, 0, 0);
-          x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j].y, bq[idx % DEPTH][j].y, x, 0, 0, 0);
+          for (int j = 0; j < 8; ++j)
+            av[j] = *reinterpret_cast<const double2_t *>(&St[16 * rt + l15][8 * j + 2 * l4]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            x[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j].x, bq[idx % DEPTH][j].x, x[rt], 0, 0, 0);
+            x[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j].y, bq[idx % DEPTH][j].y, x[rt], 0, 0, 0);
+          }
         }
         fetch_b(bq[idx % DEPTH], idx + DEPTH);
         __syncthreads();  // all reads of T done: X replaces it
 #pragma unroll
-        for (int r = 0; r < 4; ++r) St[l4 + 4 * r][16 * wc + l15] = x[r];
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) St[16 * rt + l4 + 4 * r][16 * wc + l15] = x[rt][r];
         __syncthreads();
-        for (int p = tid; p < 16 * 32; p += 256) {
+        for (int p = tid; p < 16 * RT * 32; p += 256) {
           const int row = p >> 5, c2 = (p & 31) * 2;
           const int r = r0 + row;
           if (r >= nrows || c2 >= ncol) continue;
@@ -319,10 +339,11 @@ __global__ __launch_bounds__(256) void k_trsm_block(double *K, int64_t ldk, doub
   trsm_block_body(Xs, ds, (int)blockIdx.x, K, ldk, W, ldw, nrows, c0, nb, dinv, Linv);
 }
 
-// batched: instance = tab[..] (its own N, known on the device), workgroup wg of `per`
+// batched: instance = tab[..] (its own N, known on the device), workgroup wg of `per` (32 rows each)
+#define KB_TRSM_RT 2
 __global__ __launch_bounds__(256) void kb_trsm_block(const BInst *__restrict__ tab, int B, int per,
                                                      int m, int wbuf, int c0) {
-  __shared__ __attribute__((aligned(16))) double Xs[4][16][C_LD];
+  __shared__ __attribute__((aligned(16))) double Xs[4][16 * KB_TRSM_RT][C_LD];
   __shared__ double ds[256];
   int inst, wg;
   if (!batch_decode(B, per, inst, wg)) return;
@@ -331,9 +352,9 @@ __global__ __launch_bounds__(256) void kb_trsm_block(const BInst *__restrict__ t
   const int N = I.counts[0] + m, nrows = N + 1;
   if (c0 >= N) return;
   const int nb = min(256, N - c0);
-  if (c0 + nb + 16 * wg >= nrows) return;
-  trsm_block_body(Xs, ds, wg, I.K, I.ldk, I.W + (int64_t)wbuf * I.wstride, 256, nrows, c0, nb, I.dinv,
-                  I.Linv);
+  if (c0 + nb + 16 * KB_TRSM_RT * wg >= nrows) return;
+  trsm_block_body<false, KB_TRSM_RT>(Xs, ds, wg, I.K, I.ldk, I.W + (int64_t)wbuf * I.wstride, 256, nrows, c0,
+                                     nb, I.dinv, I.Linv);
 }
 
 // ------------------------------------------------------------------ D(k)
@@ -1799,6 +1820,18 @@ void ldlt_batch_launch_chain_update(hipStream_t s, const BInst *tab, int B, int 
   }
   const int Bp = 8 * ((B + 7) / 8);
   const int tiles = per ? batch_grid(B, per) : 0;
+  // The helper workgroups (two per instance, a CU each for the length of the chain) shorten the
+  // chain from ~86 to ~70 us -- which only pays while the launch is bound by its chains: with more
+  // than ~1.5 tiles per CU (a 128 x 128 x 256 tile: ~40 us) the update tiles are the longer role
+  // and want those CUs (32 instances, N = 1280: the first two of four launches)
+  static const int ncu = []() {
+    int dev = 0, n = 256;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+      n = pr.multiProcessorCount;
+    return n;
+  }();
+  if (helpers && 2 * B * per > 3 * std::max(1, ncu - B)) helpers = false;
   if (helpers && chain_helpers())
     hipLaunchKernelGGL(kb_chain_update<true>, dim3(3 * Bp + tiles), dim3(1024), 0, s, tab, B, Bp,
                        std::max(per, 1), m, wbuf, c1, next_help_epoch());
@@ -1814,8 +1847,10 @@ void ldlt_batch_launch_chain(hipStream_t s, const BInst *tab, int B, int m, int 
   else
     hipLaunchKernelGGL(kb_diag_chain<false>, dim3(Bp), dim3(1024), 0, s, tab, B, Bp, m, c0, 0);
 }
+// per: 16-row groups of the largest possible instance below the block
 void ldlt_batch_launch_trsm(hipStream_t s, const BInst *tab, int B, int per, int m, int wbuf, int c0) {
-  hipLaunchKernelGGL(kb_trsm_block, dim3(batch_grid(B, per)), dim3(256), 0, s, tab, B, per, m, wbuf, c0);
+  const int wgs = (per + KB_TRSM_RT - 1) / KB_TRSM_RT;
+  hipLaunchKernelGGL(kb_trsm_block, dim3(batch_grid(B, wgs)), dim3(256), 0, s, tab, B, wgs, m, wbuf, c0);
 }
 
 // ------------------------------------------------------------------ host schedule
