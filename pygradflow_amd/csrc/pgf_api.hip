@@ -747,6 +747,7 @@ static int refine_if_needed(pgf_handle h, bool swapped, bool with_step = true) {
   };
   auto finish_round = [&]() -> int {
     enqueue_residual(h);
+    h->eval_fresh = false;  // the point moves: what pgf_qp_step_async evaluated ahead is stale
     if (with_step) {
       unswap();
       enqueue_step_update(h);
@@ -867,6 +868,7 @@ static int sparse_refine(pgf_handle h, bool swapped, bool with_step) {
 // failure.  swapped: the caller has already exchanged (x, y) with (xn, yn) (pgf_qp_step_async).
 static int chain_recover(pgf_handle h, bool swapped) {
   if (h->sparse || !ldlt_chain_check(h->fac)) return PGF_OK;
+  h->eval_fresh = false;  // the point is computed again
   if (swapped) {
     std::swap(h->x, h->xn);
     std::swap(h->y, h->yn);
@@ -1436,6 +1438,12 @@ int pgf_qp_step_async(pgf_handle h, unsigned policy, double tau) {
   std::swap(h->x, h->xn);
   std::swap(h->y, h->yn);
   h->eval_fresh = false;
+  // g and c at the new point, enqueued NOW: the next step needs them first thing, and behind the
+  // step's host synchronisation the four small launches would wait for the host one by one
+  // (~35 us of gaps at config 2).  Whatever moves the point afterwards (refinement, a repeated
+  // step, pgf_qp_set_point, a new rho) clears eval_fresh again.
+  static const bool ahead = !(getenv("PGF_EVAL_AHEAD") && atoi(getenv("PGF_EVAL_AHEAD")) == 0);
+  if (ahead && !h->sparse) qp_eval(h);
   if (!h->sp_stat_pending && (rc = down(h, h->h_scal, h->scal, sizeof(double)))) return rc;
   h->step_pending = true;
   return PGF_OK;
@@ -1455,10 +1463,13 @@ int pgf_qp_sync(pgf_handle h, int *n_neg, double *diff) {
     // from the point it started at
     std::swap(h->x, h->xn);
     std::swap(h->y, h->yn);
+    h->eval_fresh = false;  // (g, c were evaluated ahead at the point that is discarded)
+    qp_eval(h);
     bool did_factor;
     if ((rc = newton_core_async(h, &did_factor))) return rc;
     std::swap(h->x, h->xn);
     std::swap(h->y, h->yn);
+    h->eval_fresh = false;
     if ((rc = down(h, h->h_scal, h->scal, sizeof(double)))) return rc;
     st = finish_factor_state(h, &e);
     if (st == 2) return fail(h, PGF_HIP_ERROR, k_helper_msg);

@@ -229,6 +229,38 @@ def test_full_size_config2_properties(pgf):
     dn.close()
 
 
+def test_full_size_config2b_boxed_against_oracle(pgf):
+    """BASELINE config 2, variant 2b, at FULL size (n=4096, m=1024, 25 % of the variables boxed
+    at +-0.01): the active set is non-empty and moves, the reduced system (~5100 - |A| rows) is
+    gathered from H and J through the index lists, the right-hand side carries the H[I,A] b0
+    correction -- against the CPU oracle (scipy bmat + SuperLU, as the reference), masks bit for
+    bit, iterates to 1e-10, inertia m, for three Full steps and two Simplified back-solve steps.
+    At this size the constraint block is eliminated first."""
+    from pygradflow_amd import problems
+
+    n, m = 4096, 1024
+    prob = problems.dense_qp(n, m, seed=3, boxed_frac=0.25, box=0.01)
+    x0, y0 = np.zeros(n), np.zeros(m)
+    for pol, steps in (("Full", 3), ("Simplified", 2)):
+        recs = O.NewtonOracle(prob, pol, x0, y0, 1.0, 1.0).run(x0, y0, steps)
+        dn = pgf.DeviceNewton(prob, pol, x0, y0, 1.0, 1.0)
+        sizes = set()
+        for k, rec in enumerate(recs):
+            diff, n_neg = dn.step()
+            x, y = dn.point()
+            assert np.array_equal(dn.mask(), rec["mask"]), (pol, k)
+            assert G.rel_err(x, rec["xn"]) <= TOL, (pol, k)
+            assert G.rel_err(y, rec["yn"]) <= TOL, (pol, k)
+            assert n_neg == m, (pol, k, n_neg)
+            assert dn.factor_kind() == 2, (pol, k, dn.factor_kind())
+            sizes.add(int(rec["mask"].sum()))
+        refined, lu, _ = dn.refinement_stats()
+        assert refined == 0 and lu == 0
+        if pol == "Full":
+            assert min(sizes) > 0 and len(sizes) > 1, sizes  # active set non-empty and moving
+        dn.close()
+
+
 def test_full_size_config5_box_qp_mask_churn(pgf):
     """BASELINE config 5 at full size, dense variant 5b: box QP n=16384, m=0, ~50 % of the
     bounds active, mask churning every Full step.  The oracle runs the same problem with the
