@@ -966,8 +966,8 @@ static int newton_core_async(pgf_handle h, bool *did_factor) {
     launch_final_reduce(s, h->red, (h->n + h->m + 255) / 256, h->scal, 1);
     return PGF_OK;
   }
-  launch_reduced_rhs(s, h->n, h->m, h->nI, h->nA, h->fact, h->F, h->idxI, h->H, h->ldh, h->J,
-                     h->ldj, h->b0full, h->rhs);
+  launch_reduced_rhs(s, h->n, h->m, h->nI, h->nA, h->fact, h->F, h->idxI, h->idxA, h->H, h->ldh, h->J,
+                     h->ldj, h->b0full, h->partial, PGF_GEMVT_PARTS, h->rhs);
   *did_factor = false;
   if (!h->fac.factored) {
     int rc;
@@ -1569,6 +1569,14 @@ struct pgf_batch_s {
   BatchScalars sc{};
   bool outer_set = false, eval_fresh = false, step_pending = false, have_mask = false;
   bool all_factored = false;
+  // condensed order (constraint block eliminated first, as condensed_wanted for one instance):
+  // cond_ok = the panels exist and this batch size runs the fused schedule; cond_wanted = the
+  // growth bound holds for every instance's delta (decided per outer step on the host: the
+  // device-resident controller, which moves lambda on the device, keeps the natural order);
+  // cond_last = how the factors the instances hold were made; cond_free = the next step
+  // refactorises every instance anyway and may choose
+  bool cond_ok = false, cond_wanted = false, cond_last = false, cond_free = true;
+  int cond_mp = 0;
   int inject_helper_failure = 0;  // test hook: instance 0's next factorisation reports failed helpers
   // device-resident step controller (pgf_batch_ctl_*): per-instance state, constants, and a
   // log of (lambda used, lambda next, accepted) per outer iteration and instance
@@ -1643,6 +1651,13 @@ int pgf_batch_create(const pgf_handle *handles, int count, pgf_batch *out) {
     pgf_batch_destroy(b);
     return PGF_HIP_ERROR + (int)e;
   }
+  // the condensed order: dense handles, a constraint block worth a column block, the fused schedule
+  const bool cond_possible = condensed_mode() != 0 && !h0->sparse && h0->m > 0 && h0->m <= h0->n &&
+                             ldlt_use_lookahead() && ldlt_batch_fused_schedule(count, b->OB, false) &&
+                             (condensed_mode() == 2 ||
+                              (h0->m >= 64 && (h0->n + h0->m + 255) / 256 > (h0->n + 255) / 256));
+  b->cond_ok = cond_possible;
+  b->cond_mp = (h0->m + 31) / 32 * 32;
   for (int i = 0; i < count; ++i) {
     const pgf_handle h = handles[i];
     (void)hipStreamSynchronize(h->stream);
@@ -1697,6 +1712,18 @@ int pgf_batch_create(const pgf_handle *handles, int count, pgf_batch *out) {
     t.xpub = h->fac.xpub;
     t.cctl = h->fac.chain + 2 * h->fac.chain_stride;
     t.capblk = h->fac.chain_stride;
+    t.V = nullptr;
+    t.vd = nullptr;
+    t.ldv = 0;
+    if (cond_possible) {
+      if ((e = condensed_reserve(h)) != hipSuccess) {
+        pgf_batch_destroy(b);
+        return PGF_HIP_ERROR + (int)e;
+      }
+      t.V = h->fac.V;
+      t.vd = h->fac.vd;
+      t.ldv = (h->m + 31) / 32 * 32;
+    }
     // the batch owns the device-side state of the handle from here on
     h->mask_set = false;
     h->eval_fresh = false;
@@ -1775,6 +1802,26 @@ int pgf_batch_advance_outer_each(pgf_batch b, const double *dt, const double *rh
     h->delta = p[BPS_DELTA];
     h->outer_set = true;
   }
+  // condensed order for this outer step: the growth bound of condensed_wanted, for EVERY instance
+  // (one launch sequence serves them all)
+  b->cond_wanted = false;
+  if (b->cond_ok) {
+    static const double gmax = []() {
+      const char *e = getenv("PGF_CONDENSED_GROWTH");
+      return e ? atof(e) : 1e3;
+    }();
+    bool all = true;
+    for (int i = 0; i < b->B && all; ++i) {
+      pgf_handle h = b->hs[i];
+      if (residual_norms(h)) {
+        all = false;
+        break;
+      }
+      all = h->h_rs[6] * h->h_rs[5] <= gmax * h->delta * (h->h_rs[4] + h->lamb);
+    }
+    b->cond_wanted = all;
+  }
+  b->cond_free = true;  // every instance refactorises in the next step (new lambda)
   BHIPCHK(b, hipMemcpyAsync(b->ps, b->h_ps, (size_t)b->B * BPS_STRIDE * sizeof(double),
                             hipMemcpyHostToDevice, b->stream));
   BHIPCHK(b, hipMemcpyAsync(b->bytes, b->h_bytes, (size_t)b->B, hipMemcpyHostToDevice, b->stream));
@@ -1835,20 +1882,30 @@ static void batch_enqueue_step(pgf_batch b, unsigned policy, double tau, bool ho
   batch_eval(b);
   batch_launch_mask(b->stream, b->tab, b->B, b->sc, recompute ? (force ? 2 : 1) : 0, tau);
   b->have_mask = true;
-  batch_launch_rhs_assemble(b->stream, b->tab, b->B, b->sc);
-  const int Nmax = b->n + b->m;
+  // pivot order: free to choose when every instance refactorises (Full, or the first step of an
+  // outer step); otherwise the one the factors in place were made with
+  const bool cond = (force || b->cond_free)
+                        ? (b->cond_wanted && ldlt_batch_fused_schedule(b->B, b->OB, b->prof.enabled))
+                        : b->cond_last;
+  b->cond_last = cond;
+  b->cond_free = false;
+  batch_launch_rhs_assemble(b->stream, b->tab, b->B, b->sc, cond ? b->cond_mp : 0);
+  // (condensed: the factor and solve kernels see nI rows -- their `m' is 0)
+  const int Nmax = cond ? b->n : b->n + b->m, mf = cond ? 0 : b->m;
   // kernels of instances whose factor is still valid return at once (ctl[0] == 0); when the
   // host knows that every instance refactorises (Full) or none does, skip the other half
   const bool none_factor = !recompute && host_knows_factored;
   if (!none_factor) {
-    ldlt_batch_factor_async(b->stream, b->tab, b->B, Nmax, b->m, b->OB,
-                            b->prof.enabled ? &b->prof : nullptr);
+    ldlt_batch_factor_async(b->stream, b->tab, b->B, Nmax, mf, b->OB,
+                            b->prof.enabled ? &b->prof : nullptr, cond ? b->cond_mp : 0);
     if (b->inject_helper_failure) {
       b->inject_helper_failure = 0;
       ldlt_inject_helper_failure(b->stream, b->hs[0]->fac.flags);
     }
   }
-  ldlt_batch_solve_async(b->stream, b->tab, b->B, Nmax, b->m, !force);
+  if (cond && !force) batch_launch_cond_prep_fwd(b->stream, b->tab, b->B, b->sc);
+  ldlt_batch_solve_async(b->stream, b->tab, b->B, Nmax, mf, !force, cond);
+  if (cond) batch_launch_cond_y(b->stream, b->tab, b->B, b->sc);
   batch_launch_step_update(b->stream, b->tab, b->B, b->sc, b->diff_out, b->flags_out);
   b->eval_fresh = false;
 }
@@ -1871,6 +1928,10 @@ int pgf_batch_step_async(pgf_batch b, unsigned policy, double tau) {
   if (!recompute && force)
     return bfail(b, PGF_INVALID, "batch: PGF_STEP_REFACTOR needs PGF_STEP_RECOMPUTE_MASK");
   batch_enqueue_step(b, policy, tau, b->all_factored);
+  // g and c at the new points, enqueued ahead of the host synchronisation (as pgf_qp_step_async):
+  // behind it the five small launches would wait for the host one by one
+  static const bool ahead = !(getenv("PGF_EVAL_AHEAD") && atoi(getenv("PGF_EVAL_AHEAD")) == 0);
+  if (ahead) batch_eval(b);
   BHIPCHK(b, hipMemcpyAsync(b->h_diff, b->diff_out, b->B * sizeof(double), hipMemcpyDeviceToHost,
                             b->stream));
   BHIPCHK(b, hipMemcpyAsync(b->h_flags, b->flags_out, (size_t)b->B * 3 * sizeof(int),
@@ -1933,6 +1994,9 @@ int pgf_batch_ctl_iterate(pgf_batch b, unsigned policy, double tau, int iteratio
     // outer step of every instance at its own lambda; rejected instances go back first
     batch_launch_dctl_begin(s, b->B, b->dctl_cs, b->dctl_cp, b->ps, b->bytes);
     batch_launch_advance(s, b->tab, b->B, b->sc, b->bytes);
+    // (lambda lives on the device here: the host cannot bound the growth of the condensed order)
+    b->cond_wanted = false;
+    b->cond_free = true;
     b->eval_fresh = false;
     b->outer_set = true;
     if (!recompute) {  // Simplified: mask and derivatives frozen at the outer point
@@ -2024,7 +2088,7 @@ int pgf_batch_sync(pgf_batch b, int *status, int *n_neg, double *diff) {
     }
     all_ok = all_ok && !bad;
     if (status) status[i] = bad ? PGF_SINGULAR : PGF_OK;
-    if (n_neg) n_neg[i] = b->h_flags[3 * i + 1];
+    if (n_neg) n_neg[i] = b->h_flags[3 * i + 1] + (b->cond_last ? b->m : 0);  // (+ the m pivots -delta)
     if (diff) diff[i] = b->h_diff[i];
   }
   b->all_factored = all_ok;

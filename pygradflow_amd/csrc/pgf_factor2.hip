@@ -1644,12 +1644,10 @@ __global__ __launch_bounds__(1024) void k_update_jobs(double *K, int64_t ldk,
 // round trip) and summed through LDS in a fixed order.  Lane (l15, l4) reads four consecutive
 // doubles of its row per chunk and feeds component t to MFMA t: the sum over k does not care
 // which lane group carries which k as long as A and B agree.
-__global__ __launch_bounds__(256) void k_virtual_diag(double *K, int64_t ldk, int c0, int nb,
-                                                      const double *__restrict__ V, int64_t ldv,
-                                                      const double *__restrict__ vd, int depth, int vrows) {
-  __shared__ double part[4][4][64];
+__device__ __forceinline__ void virtual_diag_body(double (*part)[4][64], int t, double *K, int64_t ldk, int c0,
+                                                  int nb, const double *__restrict__ V, int64_t ldv,
+                                                  const double *__restrict__ vd, int depth, int vrows) {
   int ti = 0;
-  const int t = (int)blockIdx.x;
   while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
   const int tj = t - ti * (ti + 1) / 2;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
@@ -1693,6 +1691,23 @@ __global__ __launch_bounds__(256) void k_virtual_diag(double *K, int64_t ldk, in
       *p = *p + (((part[0][r][lane] + part[1][r][lane]) + part[2][r][lane]) + part[3][r][lane]);
     }
   }
+}
+__global__ __launch_bounds__(256) void k_virtual_diag(double *K, int64_t ldk, int c0, int nb,
+                                                      const double *__restrict__ V, int64_t ldv,
+                                                      const double *__restrict__ vd, int depth, int vrows) {
+  __shared__ double part[4][4][64];
+  virtual_diag_body(part, (int)blockIdx.x, K, ldk, c0, nb, V, ldv, vd, depth, vrows);
+}
+// batched: the first diagonal block of every instance that factorises (blockIdx.z = instance)
+__global__ __launch_bounds__(256) void kb_virtual_diag(const BInst *__restrict__ tab, int depth) {
+  __shared__ double part[4][4][64];
+  const BInst &I = tab[blockIdx.z];
+  if (I.ctl[0] == 0) return;
+  const int N = I.counts[0];
+  if (N <= 0) return;
+  const int nb = min(256, N), nt = (nb + 15) / 16;
+  if ((int)blockIdx.x >= nt * (nt + 1) / 2) return;
+  virtual_diag_body(part, (int)blockIdx.x, I.K, I.ldk, 0, nb, I.V, I.ldv, I.vd, depth, N + 1);
 }
 
 // ------------------------------------------------------------------ batched wrappers
@@ -1748,7 +1763,8 @@ __global__ __launch_bounds__(1024) void kb_diag_chain(const BInst *__restrict__ 
 // would queue behind them.
 template <bool HELP>
 __global__ __launch_bounds__(1024) void kb_chain_update(const BInst *__restrict__ tab, int B, int Bp,
-                                                        int per, int m, int wbuf, int c1, int epoch) {
+                                                        int per, int m, int wbuf, int c1, int epoch,
+                                                        int vdepth) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[CH_SMEM];
   const int id = (int)blockIdx.x;
   constexpr int NR = HELP ? 3 : 1;  // roles of the chain: chain, helper T, helper I
@@ -1786,8 +1802,14 @@ __global__ __launch_bounds__(1024) void kb_chain_update(const BInst *__restrict_
     ++by;
   }
   if (by >= tr) return;
-  update_tile<128, 128, 32, 4, 4, 1>(smem, threadIdx.x, row0 + 128 * by, c1 + 128 * t, I.K, I.ldk,
-                                     I.W + (int64_t)wbuf * I.wstride, 256, N, nrows, N, c1 - 256, 256);
+  if (vdepth > 0)
+    // c1 = 0, condensed order: the "previous block" is the pre-eliminated constraint block -- its
+    // panel V with the scaling -1 / delta, everything but the first diagonal block (kb_virtual_diag)
+    update_tile<128, 128, 32, 4, 4, 1, true>(smem, threadIdx.x, row0 + 128 * by, c1 + 128 * t, I.K, I.ldk, I.V,
+                                             I.ldv, N, nrows, N, 0, vdepth, I.vd);
+  else
+    update_tile<128, 128, 32, 4, 4, 1>(smem, threadIdx.x, row0 + 128 * by, c1 + 128 * t, I.K, I.ldk,
+                                       I.W + (int64_t)wbuf * I.wstride, 256, N, nrows, N, c1 - 256, 256);
 }
 
 void ldlt_batch_launch_update_diag(hipStream_t s, const BInst *tab, int B, int m, int wbuf, int c1) {
@@ -1811,7 +1833,7 @@ static int next_help_epoch() {
 }
 static bool chain_helpers();  // (below: PGF_CHAIN_HELP and the process-wide switch-off)
 void ldlt_batch_launch_chain_update(hipStream_t s, const BInst *tab, int B, int Nmax, int m, int wbuf,
-                                    int c1, bool helpers) {
+                                    int c1, bool helpers, int vdepth) {
   const int nrows = Nmax + 1, row0 = std::min(c1 + 256, Nmax);
   int per = 0;
   if (row0 < nrows) {
@@ -1834,10 +1856,13 @@ void ldlt_batch_launch_chain_update(hipStream_t s, const BInst *tab, int B, int 
   if (helpers && 2 * B * per > 3 * std::max(1, ncu - B)) helpers = false;
   if (helpers && chain_helpers())
     hipLaunchKernelGGL(kb_chain_update<true>, dim3(3 * Bp + tiles), dim3(1024), 0, s, tab, B, Bp,
-                       std::max(per, 1), m, wbuf, c1, next_help_epoch());
+                       std::max(per, 1), m, wbuf, c1, next_help_epoch(), vdepth);
   else
     hipLaunchKernelGGL(kb_chain_update<false>, dim3(Bp + tiles), dim3(1024), 0, s, tab, B, Bp,
-                       std::max(per, 1), m, wbuf, c1, 0);
+                       std::max(per, 1), m, wbuf, c1, 0, vdepth);
+}
+void ldlt_batch_launch_virtual_diag(hipStream_t s, const BInst *tab, int B, int vdepth) {
+  hipLaunchKernelGGL(kb_virtual_diag, dim3(136, 1, B), dim3(256), 0, s, tab, vdepth);
 }
 void ldlt_batch_launch_chain(hipStream_t s, const BInst *tab, int B, int m, int c0, bool helpers) {
   const int Bp = 8 * ((B + 7) / 8);

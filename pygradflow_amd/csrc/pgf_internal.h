@@ -155,6 +155,11 @@ struct BInst {
   double *xpub;
   int *cctl;
   int capblk;
+  // condensed order (pgf_api.hip, batch_condensed_wanted): the instance's panel V = J_I^T
+  // ((n + 1) x ldv, row nI = the constraint part of the right-hand side) and its scaling -1 / delta
+  double *V;
+  int64_t ldv;
+  double *vd;
 };
 
 struct BatchScalars {
@@ -202,7 +207,14 @@ void batch_launch_eval(hipStream_t s, const BInst *tab, int B, const BatchScalar
 // mode 1: adopt mask_new where it differs (or no mask yet); 2: always adopt; 0: keep
 void batch_launch_mask(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc, int mode,
                        double tau);
-void batch_launch_rhs_assemble(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc);
+// cond_mp > 0: the condensed order -- only A = H[I,I] + lamb I is assembled (+ b_x in row nI), the
+// constraint block goes into the instances' panels V (cond_mp columns, zero-padded)
+void batch_launch_rhs_assemble(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc,
+                               int cond_mp = 0);
+// condensed order: zwork <- b_x + V b_y / delta before a forward solve (instances that reuse their
+// factor), sol_y <- (V^T sol_x - b_y) / delta after the backward solve (all instances)
+void batch_launch_cond_prep_fwd(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc);
+void batch_launch_cond_y(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc);
 // flags_out: [3 i] zero-pivot flag, [3 i + 1] negative pivots, [3 i + 2] |I| of instance i
 void batch_launch_step_update(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc,
                               double *diff_out, int *flags_out);
@@ -216,13 +228,17 @@ void batch_launch_measures(hipStream_t s, const BInst *tab, int B, const BatchSc
 void ldlt_batch_launch_chain(hipStream_t s, const BInst *tab, int B, int m, int c0, bool helpers);
 void ldlt_batch_launch_update_diag(hipStream_t s, const BInst *tab, int B, int m, int wbuf, int c1);
 void ldlt_batch_launch_chain_update(hipStream_t s, const BInst *tab, int B, int Nmax, int m, int wbuf,
-                                    int c1, bool helpers);
+                                    int c1, bool helpers, int vdepth = 0);
+void ldlt_batch_launch_virtual_diag(hipStream_t s, const BInst *tab, int B, int vdepth);
+// the batched factorisation runs the fused look-ahead schedule for this batch size (the only one
+// that knows the condensed order)
+bool ldlt_batch_fused_schedule(int B, int OB, bool profiling);
 void ldlt_batch_launch_trsm(hipStream_t s, const BInst *tab, int B, int per, int m, int wbuf, int c0);
 void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m, int OB,
-                             PgfProfile *prof);
+                             PgfProfile *p, int vdepth = 0);
 bool ldlt_chain_enabled();  // chained solves requested (PGF_TRSV_CHAIN) and not switched off
 void ldlt_batch_solve_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m,
-                            bool any_unfactored_solve);
+                            bool any_unfactored_solve, bool cond_prep = false);
 
 // ---- elementwise / assembly launches (pgf_kernels.hip) --------------------
 struct StepDev;  // opaque here

@@ -16,8 +16,8 @@ void launch_residual(hipStream_t s, int n, int m, double lamb, double dt, const 
                      const double *c, const double *slb, const double *sub, const uint8_t *mask,
                      double *F, double *b0full);
 void launch_reduced_rhs(hipStream_t s, int n, int m, int nI, int nA, double fact, const double *F,
-                        const int *idxI, const double *H, int64_t ldh, const double *J,
-                        int64_t ldj, const double *b0full, double *rhs);
+                        const int *idxI, const int *idxA, const double *H, int64_t ldh, const double *J,
+                        int64_t ldj, const double *b0full, double *partial, int nparts, double *rhs);
 void launch_assemble_kkt(hipStream_t s, double *K, int64_t ldk, const double *H, int64_t ldh,
                          const double *J, int64_t ldj, const int *idxI, int nI, int m,
                          double lamb, double delta);

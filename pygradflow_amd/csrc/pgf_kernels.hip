@@ -149,30 +149,50 @@ __device__ __forceinline__ double row_dot(const double *__restrict__ row,
 //   i >= nI : rhs[i] = fact * F[n + r]    - J[r, :]    . b0full      (r = i - nI)
 // b0full is zero on the inactive set, so the full-row dot equals the reference's
 // H_lamb[I, A] b0 / J[:, A] b0 (symmetric_step_solver.py:87-91); skipped when |A| = 0.
+// The H part reads the ACTIVE rows instead of the inactive ones (H is symmetric:
+// H[I, A] b0 = (H[A, I])^T b0): |A| n instead of |I| n entries -- b_active_rows_partial leaves
+// partial[p][j] = sum over the active rows a of chunk p of H[a][j] b0[a], fixed chunks, and the
+// rows i < nI pick their column out of it.  (One row-dot per inactive row read 90 % of every
+// instance's H in a batch with 10 % active variables: 53 us of a 1.3 ms batched step.)
+__device__ __forceinline__ void b_active_rows_partial(int n, int nA, const int *__restrict__ idxA,
+                                                      const double *__restrict__ H, int64_t ldh,
+                                                      const double *__restrict__ b0full, int nparts,
+                                                      double *__restrict__ partial) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n || nA <= 0) return;
+  const int chunk = (nA + nparts - 1) / nparts;
+  const int a0 = blockIdx.y * chunk, a1 = min(nA, a0 + chunk);
+  double acc = 0.0;
+  for (int a = a0; a < a1; ++a) {
+    const int ga = idxA[a];
+    acc = fma(H[(int64_t)ga * ldh + j], b0full[ga], acc);
+  }
+  partial[(int64_t)blockIdx.y * n + j] = acc;
+}
 __device__ __forceinline__ void b_reduced_rhs(int n, int m, int nI, int nA, double fact,
                                                      const double *__restrict__ F,
                                                      const int *__restrict__ idxI,
-                                                     const double *__restrict__ H, int64_t ldh,
                                                      const double *__restrict__ J, int64_t ldj,
                                                      const double *__restrict__ b0full,
+                                                     const double *__restrict__ partial, int nparts,
                                                      double *__restrict__ rhs) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= nI + m) return;
-  double base;
-  const double *row;
   if (i < nI) {
     const int gi = idxI[i];
-    base = F[gi];
-    row = H + (int64_t)gi * ldh;
-  } else {
-    const int r = i - nI;
-    base = fact * F[n + r];
-    row = J + (int64_t)r * ldj;
+    double corr = 0.0;
+    if (nA > 0) {  // lane p takes chunk p (nparts <= 64), summed over the wavefront in a fixed order
+      corr = lane < nparts ? partial[(int64_t)lane * n + gi] : 0.0;
+      corr = wave_sum(corr);
+    }
+    if (lane == 0) rhs[i] = F[gi] - corr;
+    return;
   }
+  const int r = i - nI;
   double corr = 0.0;
-  if (nA > 0) corr = row_dot(row, b0full, n, lane);
-  if (lane == 0) rhs[i] = base - corr;
+  if (nA > 0) corr = row_dot(J + (int64_t)r * ldj, b0full, n, lane);
+  if (lane == 0) rhs[i] = fact * F[n + r] - corr;
 }
 
 // ---------------------------------------------------------------- K assembly (a10, a12)
@@ -193,23 +213,33 @@ __device__ __forceinline__ void b_assemble_kkt(double *__restrict__ K, int64_t l
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= N || j > i0 + ROWS - 1) return;
   const int gj = (j < nI) ? idxI[j] : 0;
+  // eight rows at a time: all loads of the group first, then the stores (one row after the other
+  // the loop ran a dependent load -> store chain per row: 113 us for a batch of 32 x 1280^2)
+  constexpr int G = ROWS < 8 ? ROWS : 8;
 #pragma unroll
-  for (int r = 0; r < ROWS; ++r) {
-    const int i = i0 + r;
-    if (i >= N) break;
-    if (j > i) continue;
-    double v;
-    if (i < nI) {
-      v = H[(int64_t)idxI[i] * ldh + gj];
-      if (i == j) v = v + lamb;
-    } else {
-      const int rr = i - nI;
-      if (j < nI)
-        v = J[(int64_t)rr * ldj + gj];
-      else
-        v = (j == i) ? -delta : 0.0;
+  for (int r0 = 0; r0 < ROWS; r0 += G) {
+    double v[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int i = i0 + r0 + u;
+      v[u] = 0.0;
+      if (i < N && j <= i) {
+        if (i < nI) {
+          v[u] = H[(int64_t)idxI[i] * ldh + gj];
+        } else if (j < nI) {
+          v[u] = J[(int64_t)(i - nI) * ldj + gj];
+        }
+      }
     }
-    K[(int64_t)i * ldk + j] = v;
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int i = i0 + r0 + u;
+      if (i < N && j <= i) {
+        double w = v[u];
+        if (i == j) w = (i < nI) ? w + lamb : -delta;
+        K[(int64_t)i * ldk + j] = w;
+      }
+    }
   }
 }
 
@@ -482,11 +512,16 @@ __global__ void k_residual(int n, int m, double lamb, double dt, const double *_
   b_residual(n, m, lamb, dt, xhat, yhat, x, y, g, c, slb, sub, mask, F, b0full);
 }
 
+__global__ __launch_bounds__(256) void k_active_rows_partial(int n, int nA, const int *__restrict__ idxA,
+    const double *__restrict__ H, int64_t ldh, const double *__restrict__ b0full, int nparts,
+    double *__restrict__ partial) {
+  b_active_rows_partial(n, nA, idxA, H, ldh, b0full, nparts, partial);
+}
 __global__ __launch_bounds__(256) void k_reduced_rhs(int n, int m, int nI, int nA, double fact,
-    const double *__restrict__ F, const int *__restrict__ idxI, const double *__restrict__ H,
-    int64_t ldh, const double *__restrict__ J, int64_t ldj, const double *__restrict__ b0full,
+    const double *__restrict__ F, const int *__restrict__ idxI, const double *__restrict__ J,
+    int64_t ldj, const double *__restrict__ b0full, const double *__restrict__ partial, int nparts,
     double *__restrict__ rhs) {
-  b_reduced_rhs(n, m, nI, nA, fact, F, idxI, H, ldh, J, ldj, b0full, rhs);
+  b_reduced_rhs(n, m, nI, nA, fact, F, idxI, J, ldj, b0full, partial, nparts, rhs);
 }
 
 __global__ __launch_bounds__(256) void k_assemble_kkt(double *__restrict__ K, int64_t ldk,
@@ -584,12 +619,15 @@ void launch_residual(hipStream_t s, int n, int m, double lamb, double dt, const 
 }
 
 void launch_reduced_rhs(hipStream_t s, int n, int m, int nI, int nA, double fact, const double *F,
-                        const int *idxI, const double *H, int64_t ldh, const double *J,
-                        int64_t ldj, const double *b0full, double *rhs) {
+                        const int *idxI, const int *idxA, const double *H, int64_t ldh, const double *J,
+                        int64_t ldj, const double *b0full, double *partial, int nparts, double *rhs) {
   const int N = nI + m;
-  if (N)
-    hipLaunchKernelGGL(k_reduced_rhs, dim3((N + 3) / 4), dim3(256), 0, s, n, m, nI, nA, fact, F,
-                       idxI, H, ldh, J, ldj, b0full, rhs);
+  if (!N) return;
+  if (nA > 0 && nI > 0)
+    hipLaunchKernelGGL(k_active_rows_partial, dim3((n + 255) / 256, nparts), dim3(256), 0, s, n, nA, idxA,
+                       H, ldh, b0full, nparts, partial);
+  hipLaunchKernelGGL(k_reduced_rhs, dim3((N + 3) / 4), dim3(256), 0, s, n, m, nI, nA, fact, F, idxI, J,
+                     ldj, b0full, partial, nparts, rhs);
 }
 
 void launch_assemble_kkt(hipStream_t s, double *K, int64_t ldk, const double *H, int64_t ldh,
@@ -957,12 +995,18 @@ __global__ void kb_residual(const BInst *__restrict__ tab, int n, int m) {
              I.b0full);
 }
 
-__global__ __launch_bounds__(256) void kb_reduced_rhs(const BInst *__restrict__ tab, int n,
-                                                      int m) {
+__global__ __launch_bounds__(256) void kb_active_rows_partial(const BInst *__restrict__ tab, int n,
+                                                              int nparts) {
   const BInst &I = tab[blockIdx.z];
   if (I.ctl[3]) return;
-  b_reduced_rhs(n, m, I.counts[0], I.counts[1], I.ps[BPS_FACT], I.F, I.idxI, I.H, I.ldh, I.J, I.ldj,
-                I.b0full, I.rhs);
+  b_active_rows_partial(n, I.counts[1], I.idxA, I.H, I.ldh, I.b0full, nparts, I.partial);
+}
+__global__ __launch_bounds__(256) void kb_reduced_rhs(const BInst *__restrict__ tab, int n,
+                                                      int m, int nparts) {
+  const BInst &I = tab[blockIdx.z];
+  if (I.ctl[3]) return;
+  b_reduced_rhs(n, m, I.counts[0], I.counts[1], I.ps[BPS_FACT], I.F, I.idxI, I.J, I.ldj, I.b0full,
+                I.partial, nparts, I.rhs);
 }
 
 // K (lower triangle) + the right-hand side in row N, only for instances that factorise
@@ -1236,13 +1280,106 @@ void batch_launch_mask(hipStream_t s, const BInst *tab, int B, const BatchScalar
   hipLaunchKernelGGL(kb_mask_adopt, dim3(1, 1, B), dim3(1024), 0, s, tab, sc.n, mode);
 }
 
-void batch_launch_rhs_assemble(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc) {
+// ---- condensed order, batched (single-instance twins: k_cond_* at the end of this file) -------
+// V[i][r] = J[r][idxI[i]], zero beyond m; instances that factorise this step only
+__global__ __launch_bounds__(256) void kb_cond_panel(const BInst *__restrict__ tab, int m, int mp) {
+  const BInst &I = tab[blockIdx.z];
+  if (I.ctl[0] == 0) return;
+  const int nI = I.counts[0];
+  const int i0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  if (i0 >= nI) return;
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int i = i0 + tx;
+  const int col = i < nI ? I.idxI[i] : 0;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = r0 + ty + 8 * p;
+    tile[ty + 8 * p][tx] = (r < m && i < nI) ? I.J[(int64_t)r * I.ldj + col] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int ii = i0 + ty + 8 * p, r = r0 + tx;
+    if (ii < nI && r < mp) I.V[(int64_t)ii * I.ldv + r] = tile[tx][ty + 8 * p];
+  }
+}
+// row nI of V <- b_y, vd <- -1 / delta
+__global__ void kb_cond_tail(const BInst *__restrict__ tab, int m, int mp) {
+  const BInst &I = tab[blockIdx.z];
+  if (I.ctl[0] == 0) return;
+  const int nI = I.counts[0];
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= mp) return;
+  I.V[(int64_t)nI * I.ldv + r] = (r < m) ? I.rhs[nI + r] : 0.0;
+  I.vd[r] = -1.0 / I.ps[BPS_DELTA];
+}
+// zwork[i] = b_x[i] + dot(V[i][0:m], b_y) / delta: the forward solve's input when the factor is reused
+__global__ __launch_bounds__(256) void kb_cond_prep_fwd(const BInst *__restrict__ tab, int m) {
+  const BInst &I = tab[blockIdx.z];
+  if (I.ctl[0] != 0 || I.ctl[3]) return;
+  const int nI = I.counts[0];
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= nI) return;
+  const double d = row_dot(I.V + (int64_t)i * I.ldv, I.rhs + nI, m, lane);
+  if (lane == 0) I.zwork[i] = I.rhs[i] + d / I.ps[BPS_DELTA];
+}
+// sol_y[r] = (sum_i V[i][r] sol_x[i] - b_y[r]) / delta: 64 columns per workgroup, sixteen lane
+// groups take the rows i = g, g + 16, ... (four loads in flight each) and are summed in a fixed order
+__global__ __launch_bounds__(1024) void kb_cond_y(const BInst *__restrict__ tab, int m) {
+  const BInst &I = tab[blockIdx.z];
+  if (I.ctl[3]) return;
+  __shared__ double part[16][64];
+  const int nI = I.counts[0];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int r = blockIdx.x * 64 + c;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (r < m) {
+    const double *__restrict__ v = I.V + r;
+    const double *__restrict__ x = I.sol;
+    const int64_t ld = I.ldv;
+    int i = g;
+    for (; i + 48 < nI; i += 64) {
+      s0 = fma(v[(int64_t)i * ld], x[i], s0);
+      s1 = fma(v[(int64_t)(i + 16) * ld], x[i + 16], s1);
+      s2 = fma(v[(int64_t)(i + 32) * ld], x[i + 32], s2);
+      s3 = fma(v[(int64_t)(i + 48) * ld], x[i + 48], s3);
+    }
+    for (; i < nI; i += 16) s0 = fma(v[(int64_t)i * ld], x[i], s0);
+  }
+  part[g][c] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g == 0 && r < m) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += part[k][c];
+    I.sol[nI + r] = (s - I.rhs[nI + r]) / I.ps[BPS_DELTA];
+  }
+}
+
+void batch_launch_rhs_assemble(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc, int cond_mp) {
   const int n = sc.n, m = sc.m, Nmax = n + m;
   if (!Nmax) return;
   hipLaunchKernelGGL(kb_residual, gb(Nmax, 256, B), dim3(256), 0, s, tab, n, m);
-  hipLaunchKernelGGL(kb_reduced_rhs, gb(Nmax, 4, B), dim3(256), 0, s, tab, n, m);
+  // (the scratch `partial' holds 32 n doubles per instance: PGF_GEMVT_PARTS in pgf_api.hip)
+  if (n) hipLaunchKernelGGL(kb_active_rows_partial, dim3((n + 255) / 256, 32, B), dim3(256), 0, s, tab, n, 32);
+  hipLaunchKernelGGL(kb_reduced_rhs, gb(Nmax, 4, B), dim3(256), 0, s, tab, n, m, 32);
+  if (cond_mp > 0) {
+    // A and b_x (the assembly kernel with no constraint rows), V, b_y
+    hipLaunchKernelGGL(kb_assemble, dim3((n + 255) / 256, n / KB_ASM_ROWS + 1, B), dim3(256), 0, s, tab, 0);
+    hipLaunchKernelGGL(kb_cond_panel, dim3((n + 31) / 32, cond_mp / 32, B), dim3(256), 0, s, tab, m, cond_mp);
+    hipLaunchKernelGGL(kb_cond_tail, gb(cond_mp, 256, B), dim3(256), 0, s, tab, m, cond_mp);
+    return;
+  }
   hipLaunchKernelGGL(kb_assemble, dim3((Nmax + 255) / 256, Nmax / KB_ASM_ROWS + 1, B), dim3(256), 0,
                      s, tab, m);
+}
+void batch_launch_cond_prep_fwd(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc) {
+  if (sc.n) hipLaunchKernelGGL(kb_cond_prep_fwd, gb(sc.n, 4, B), dim3(256), 0, s, tab, sc.m);
+}
+void batch_launch_cond_y(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc) {
+  if (sc.m) hipLaunchKernelGGL(kb_cond_y, dim3((sc.m + 63) / 64, 1, B), dim3(1024), 0, s, tab, sc.m);
 }
 
 void batch_launch_step_update(hipStream_t s, const BInst *tab, int B, const BatchScalars &sc,

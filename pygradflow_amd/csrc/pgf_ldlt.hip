@@ -1585,8 +1585,22 @@ hipError_t ldlt_solve_async(DenseLdlt &f, const double *rhs, double *sol) {
 }
 
 // ------------------------------------------------------------------ batched host schedule
+static bool batch_chain_sched() {
+  static const bool on = !(getenv("PGF_BATCH_CHAIN") && atoi(getenv("PGF_BATCH_CHAIN")) == 0);
+  return on;
+}
+static int batch_fused_max() {
+  static const int v = getenv("PGF_BATCH_FUSED_MAX") ? atoi(getenv("PGF_BATCH_FUSED_MAX")) : 64;
+  return v;
+}
+bool ldlt_batch_fused_schedule(int B, int OB, bool profiling) {
+  return OB == 256 && batch_chain_sched() && B <= batch_fused_max() && !profiling;
+}
+
+// vdepth > 0 (fused look-ahead schedule only): every instance's K is preceded by a pre-eliminated
+// block with panel BInst::V (the condensed order, pgf_api.hip); m is then 0 for the factor kernels
 void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m, int OB,
-                             PgfProfile *p) {
+                             PgfProfile *p, int vdepth) {
   if (Nmax <= 0 || B <= 0) return;
   // PGF_BATCH_LL=0: the single-instance schedule with a batch dimension (fused panel
   // kernel + K = 64 inner updates); default: the left-looking split panel step
@@ -1597,18 +1611,24 @@ void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, i
   // small batch is bound by the number of dependent launches, not by throughput -- a rank of
   // an 8-GPU run of BASELINE config 4 holds 32 instances: 1.98 -> 1.71 ms per batched step;
   // 256 instances: 8.48 -> 8.17 ms.
-  static const bool chain_sched = !(getenv("PGF_BATCH_CHAIN") && atoi(getenv("PGF_BATCH_CHAIN")) == 0);
+  const bool chain_sched = batch_chain_sched();
   // small batches (PGF_BATCH_FUSED_MAX, default 64 instances): the single-instance look-ahead
   // too -- the next block's chains run beside the previous block's bulk update in one launch
   // (k_update_diag first), most CUs being idle during a chain launch of a few workgroups
-  static const int fused_max = getenv("PGF_BATCH_FUSED_MAX") ? atoi(getenv("PGF_BATCH_FUSED_MAX")) : 64;
-  if (OB == 256 && chain_sched && B <= fused_max && !p) {
+  if (ldlt_batch_fused_schedule(B, OB, p != nullptr)) {
     // chain helpers (three workgroups per instance, resident together) up to 32 instances:
     // 8: 0.96 -> 0.83 ms, 16: 1.09 -> 0.98, 32: 1.56 -> 1.52; at 64 they cost more CUs than
     // they save chain time (2.52 -> 2.57)
     const bool helpers = B <= 32;
     int buf = 0;
-    ldlt_batch_launch_chain(s, tab, B, m, 0, helpers);
+    if (vdepth > 0) {
+      // condensed order: the rank-m term's update of the first diagonal block, then the first
+      // chains BESIDE its update of everything else (they used to run alone, the chip idle)
+      ldlt_batch_launch_virtual_diag(s, tab, B, vdepth);
+      ldlt_batch_launch_chain_update(s, tab, B, Nmax, m, 0, 0, helpers, vdepth);
+    } else {
+      ldlt_batch_launch_chain(s, tab, B, m, 0, helpers);
+    }
     if (Nmax + 1 - std::min(OB, Nmax) > 0)
       ldlt_batch_launch_trsm(s, tab, B, (Nmax + 1 - std::min(OB, Nmax) + 15) / 16, m, 0, 0);
     for (int c0 = 0; c0 + OB < Nmax; c0 += OB, buf ^= 1) {
@@ -1717,15 +1737,16 @@ __global__ __launch_bounds__(256, 3) void kb_trsv_fwd_chain(const BInst *__restr
   chain_fwd_body(I.K, I.ldk, I.LinvT, I.zwork, I.sol, N, I.xpub, I.capblk, I.cctl, w);
 }
 
+// cond_prep: the caller has filled zwork for the forward solves itself (condensed order)
 void ldlt_batch_solve_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m,
-                            bool any_unfactored_solve) {
+                            bool any_unfactored_solve, bool cond_prep) {
   if (Nmax <= 0 || B <= 0) return;
   const dim3 gv((Nmax + 255) / 256, 1, B);
   if (use_chain()) {
     const int nwmax = (Nmax + 63) / 64;
     const dim3 gc(8 * ((B + 7) / 8) * nwmax);
     if (any_unfactored_solve) {
-      hipLaunchKernelGGL(kb_solve_prep_fwd, gv, dim3(256), 0, s, tab, m);
+      if (!cond_prep) hipLaunchKernelGGL(kb_solve_prep_fwd, gv, dim3(256), 0, s, tab, m);
       hipLaunchKernelGGL(kb_trsv_fwd_chain, gc, dim3(256), 0, s, tab, B, m, nwmax);
     }
     hipLaunchKernelGGL(kb_solve_prep_bwd, gv, dim3(256), 0, s, tab, m);
@@ -1733,7 +1754,7 @@ void ldlt_batch_solve_async(hipStream_t s, const BInst *tab, int B, int Nmax, in
     return;
   }
   if (any_unfactored_solve) {
-    hipLaunchKernelGGL(kb_solve_prep_fwd, gv, dim3(256), 0, s, tab, m);
+    if (!cond_prep) hipLaunchKernelGGL(kb_solve_prep_fwd, gv, dim3(256), 0, s, tab, m);
     for (int c0 = 0; c0 < Nmax; c0 += 256) {
       const int below = Nmax - (c0 + 256);
       const int g = below > 0 ? (below + 63) / 64 : 1;

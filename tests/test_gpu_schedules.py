@@ -31,6 +31,8 @@ BATCH_VARIANTS = {
     "chain_per_block": {"PGF_BATCH_FUSED_MAX": "0"},  # what larger batches run
     "split_panel_steps": {"PGF_BATCH_CHAIN": "0"},    # the round-1 schedule
     "solves_per_super_block": {"PGF_TRSV_CHAIN": "0"},  # batched solves without the chained kernels
+    "condensed_order": {"PGF_CONDENSED": "2"},        # constraint block first (what n=1024, m=256 runs by default)
+    "natural_order": {"PGF_CONDENSED": "0"},
 }
 
 
