@@ -1570,7 +1570,7 @@ struct pgf_batch_s {
   bool outer_set = false, eval_fresh = false, step_pending = false, have_mask = false;
   bool all_factored = false;
   // condensed order (constraint block eliminated first, as condensed_wanted for one instance):
-  // cond_ok = the panels exist and this batch size runs the fused schedule; cond_wanted = the
+  // cond_ok = the panels exist and the batch runs one of the chain schedules; cond_wanted = the
   // growth bound holds for every instance's delta (decided per outer step on the host: the
   // device-resident controller, which moves lambda on the device, keeps the natural order);
   // cond_last = how the factors the instances hold were made; cond_free = the next step
@@ -1653,7 +1653,7 @@ int pgf_batch_create(const pgf_handle *handles, int count, pgf_batch *out) {
   }
   // the condensed order: dense handles, a constraint block worth a column block, the fused schedule
   const bool cond_possible = condensed_mode() != 0 && !h0->sparse && h0->m > 0 && h0->m <= h0->n &&
-                             ldlt_use_lookahead() && ldlt_batch_fused_schedule(count, b->OB, false) &&
+                             ldlt_use_lookahead() && ldlt_batch_condensed_schedule(b->OB) &&
                              (condensed_mode() == 2 ||
                               (h0->m >= 64 && (h0->n + h0->m + 255) / 256 > (h0->n + 255) / 256));
   b->cond_ok = cond_possible;
@@ -1884,9 +1884,7 @@ static void batch_enqueue_step(pgf_batch b, unsigned policy, double tau, bool ho
   b->have_mask = true;
   // pivot order: free to choose when every instance refactorises (Full, or the first step of an
   // outer step); otherwise the one the factors in place were made with
-  const bool cond = (force || b->cond_free)
-                        ? (b->cond_wanted && ldlt_batch_fused_schedule(b->B, b->OB, b->prof.enabled))
-                        : b->cond_last;
+  const bool cond = (force || b->cond_free) ? b->cond_wanted : b->cond_last;
   b->cond_last = cond;
   b->cond_free = false;
   batch_launch_rhs_assemble(b->stream, b->tab, b->B, b->sc, cond ? b->cond_mp : 0);
@@ -2115,10 +2113,14 @@ int pgf_batch_profile_read(pgf_batch b, double *update_ms, int64_t *update_launc
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, p.update_spans[i].first, p.update_spans[i].second) == hipSuccess)
       ms_sum += ms;
+    // update_flops[i] >= 0: first row of the launch's trailing region, K-depth OB; < 0: the rank-m
+    // launch of the condensed order over the whole lower triangle, K-depth = -value
     const double start = p.update_flops[i];
     for (int k = 0; k < b->B; ++k) {
-      const double T = (double)(b->h_flags[3 * k + 2] + b->m) - start;
-      if (T > 0) fl_sum += 2.0 * b->OB * (0.5 * T * (T + 1.0) + T);
+      const double Nk = (double)(b->h_flags[3 * k + 2] + (b->cond_last ? 0 : b->m));
+      const double T = start < 0 ? Nk : Nk - start;
+      const double depth = start < 0 ? -start : (double)b->OB;
+      if (T > 0) fl_sum += 2.0 * depth * (0.5 * T * (T + 1.0) + T);
     }
     p.pool.push_back(p.update_spans[i].first);
     p.pool.push_back(p.update_spans[i].second);

@@ -233,6 +233,7 @@ void ldlt_batch_launch_virtual_diag(hipStream_t s, const BInst *tab, int B, int 
 // the batched factorisation runs the fused look-ahead schedule for this batch size (the only one
 // that knows the condensed order)
 bool ldlt_batch_fused_schedule(int B, int OB, bool profiling);
+bool ldlt_batch_condensed_schedule(int OB);
 void ldlt_batch_launch_trsm(hipStream_t s, const BInst *tab, int B, int per, int m, int wbuf, int c0);
 void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, int m, int OB,
                              PgfProfile *p, int vdepth = 0);

@@ -884,6 +884,22 @@ __global__ __launch_bounds__(256) void kb_ldlt_update(const BInst *__restrict__ 
   update_tile<64, 64, 16>(smem, threadIdx.x, i0, j0, I.K, I.ldk,
                           I.W + (int64_t)wbuf * I.wstride + wcol, ldw, N, nrows, colEnd, kc0, KB);
 }
+// the same tiles for a pre-eliminated block (condensed order): C -= (V vd) V^T over the whole
+// lower triangle (+ row N), depth KB, operands from the instance's panel
+__global__ __launch_bounds__(256) void kb_ldlt_update_virtual(const BInst *__restrict__ tab, int B, int tc,
+                                                              int tr, int KB) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(64 + 64) * (16 + 2) * 8];
+  int inst, t;
+  if (!batch_decode(B, tc * tr, inst, t)) return;
+  const BInst &I = tab[inst];
+  if (I.ctl[0] == 0) return;
+  const int N = I.counts[0], nrows = N + 1;
+  const int by = t / tc, bx = t - by * tc;
+  const int i0 = by * 64, j0 = bx * 64;
+  if (i0 >= nrows || j0 >= N || j0 > i0 + 63) return;
+  update_tile<64, 64, 16, 2, 2, 0, true>(smem, threadIdx.x, i0, j0, I.K, I.ldk, I.V, I.ldv, N, nrows, N, 0, KB,
+                                         I.vd);
+}
 
 // ---- left-looking panel step of the batched schedule --------------------------------------
 // In batched mode throughput counts, not the latency of one panel, so the panel step is split:
@@ -1596,6 +1612,8 @@ static int batch_fused_max() {
 bool ldlt_batch_fused_schedule(int B, int OB, bool profiling) {
   return OB == 256 && batch_chain_sched() && B <= batch_fused_max() && !profiling;
 }
+// the schedules that know the condensed order (vdepth > 0): the two chain schedules
+bool ldlt_batch_condensed_schedule(int OB) { return OB == 256 && batch_chain_sched(); }
 
 // vdepth > 0 (fused look-ahead schedule only): every instance's K is preceded by a pre-eliminated
 // block with panel BInst::V (the condensed order, pgf_api.hip); m is then 0 for the factor kernels
@@ -1642,6 +1660,24 @@ void ldlt_batch_factor_async(hipStream_t s, const BInst *tab, int B, int Nmax, i
   }
   if (OB == 256 && chain_sched) {
     int buf = 0;
+    if (vdepth > 0) {
+      // condensed order: the rank-m term on the whole lower triangle first (the chains of a large
+      // batch fill the chip: nothing to run it beside)
+      const int tr = (Nmax + 1 + 63) / 64, tc = (Nmax + 63) / 64;
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (p) {
+        e0 = prof_event(p);
+        e1 = prof_event(p);
+        (void)hipEventRecord(e0, s);
+      }
+      hipLaunchKernelGGL(kb_ldlt_update_virtual, dim3(batch_grid(B, tc * tr)), dim3(256), 0, s, tab, B, tc, tr,
+                         vdepth);
+      if (p) {
+        (void)hipEventRecord(e1, s);
+        p->update_spans.emplace_back(e0, e1);
+        p->update_flops.push_back(-(double)vdepth);  // (marks the virtual launch: pgf_batch_profile_read)
+      }
+    }
     for (int ob0 = 0; ob0 < Nmax; ob0 += OB, buf ^= 1) {
       const int obEnd = std::min(ob0 + OB, Nmax);
       ldlt_batch_launch_chain(s, tab, B, m, ob0, false);

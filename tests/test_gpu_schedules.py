@@ -33,6 +33,7 @@ BATCH_VARIANTS = {
     "solves_per_super_block": {"PGF_TRSV_CHAIN": "0"},  # batched solves without the chained kernels
     "condensed_order": {"PGF_CONDENSED": "2"},        # constraint block first (what n=1024, m=256 runs by default)
     "natural_order": {"PGF_CONDENSED": "0"},
+    "condensed_chain_per_block": {"PGF_CONDENSED": "2", "PGF_BATCH_FUSED_MAX": "0"},  # large batches
 }
 
 
