@@ -211,10 +211,16 @@ __device__ __forceinline__ void b_assemble_kkt(double *__restrict__ K, int64_t l
   const int N = nI + m;
   const int i0 = blockIdx.y * ROWS;
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= N || j > i0 + ROWS - 1) return;
+  if ((int)blockIdx.x * 256 >= N || (int)blockIdx.x * 256 > i0 + ROWS - 1) return;  // (whole workgroups only:
+                                                             // every lane may be asked for its row index)
   const int gj = (j < nI) ? idxI[j] : 0;
-  // eight rows at a time: all loads of the group first, then the stores (one row after the other
-  // the loop ran a dependent load -> store chain per row: 113 us for a batch of 32 x 1280^2)
+  // The rows' indices in H come from ONE vector load (lane u holds row i0 + u's) and reach the
+  // scalar unit through v_readlane: looked up row by row (`idxI[i]', a scalar load and its wait in
+  // front of every row's global load) the rows ran one after the other -- 0.9 ms for a batch of
+  // 256 x 1024^2, 2.4 TB/s.  Eight rows at a time: all loads of the group, then the stores.
+  static_assert(ROWS <= 64, "one lane per row of the workgroup");
+  const int lane = threadIdx.x & 63;
+  const int rowidx = (lane < ROWS && i0 + lane < nI) ? idxI[i0 + lane] : 0;
   constexpr int G = ROWS < 8 ? ROWS : 8;
 #pragma unroll
   for (int r0 = 0; r0 < ROWS; r0 += G) {
@@ -222,10 +228,11 @@ __device__ __forceinline__ void b_assemble_kkt(double *__restrict__ K, int64_t l
 #pragma unroll
     for (int u = 0; u < G; ++u) {
       const int i = i0 + r0 + u;
+      const int gi = __builtin_amdgcn_readlane(rowidx, r0 + u);
       v[u] = 0.0;
-      if (i < N && j <= i) {
+      if (i < N && j <= i && j < N) {
         if (i < nI) {
-          v[u] = H[(int64_t)idxI[i] * ldh + gj];
+          v[u] = H[(int64_t)gi * ldh + gj];
         } else if (j < nI) {
           v[u] = J[(int64_t)(i - nI) * ldj + gj];
         }
@@ -234,7 +241,7 @@ __device__ __forceinline__ void b_assemble_kkt(double *__restrict__ K, int64_t l
 #pragma unroll
     for (int u = 0; u < G; ++u) {
       const int i = i0 + r0 + u;
-      if (i < N && j <= i) {
+      if (i < N && j <= i && j < N) {
         double w = v[u];
         if (i == j) w = (i < nI) ? w + lamb : -delta;
         K[(int64_t)i * ldk + j] = w;
