@@ -1698,16 +1698,59 @@ __global__ __launch_bounds__(256) void k_virtual_diag(double *K, int64_t ldk, in
   __shared__ double part[4][4][64];
   virtual_diag_body(part, (int)blockIdx.x, K, ldk, c0, nb, V, ldv, vd, depth, vrows);
 }
-// batched: the first diagonal block of every instance that factorises (blockIdx.z = instance)
+// batched: the first diagonal block of every instance that factorises (blockIdx.z = instance).
+// Throughput, not the latency of one tile: a wavefront takes one 16 x 16 tile over the whole
+// depth, four chunks (64 columns) in flight -- 34 workgroups per instance, all of a small batch
+// resident at once (the split-depth version above: 4352 workgroups for 32 instances, 42 us).
 __global__ __launch_bounds__(256) void kb_virtual_diag(const BInst *__restrict__ tab, int depth) {
-  __shared__ double part[4][4][64];
   const BInst &I = tab[blockIdx.z];
   if (I.ctl[0] == 0) return;
   const int N = I.counts[0];
   if (N <= 0) return;
   const int nb = min(256, N), nt = (nb + 15) / 16;
-  if ((int)blockIdx.x >= nt * (nt + 1) / 2) return;
-  virtual_diag_body(part, (int)blockIdx.x, I.K, I.ldk, 0, nb, I.V, I.ldv, I.vd, depth, N + 1);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int t = 4 * (int)blockIdx.x + wave;
+  if (t >= nt * (nt + 1) / 2) return;
+  int ti = 0;
+  while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+  const int tj = t - ti * (ti + 1) / 2;
+  const int i0 = 16 * ti, j0 = 16 * tj;
+  const double *pa = I.V + (int64_t)min(i0 + l15, N) * I.ldv + 4 * l4;
+  const double *pb = I.V + (int64_t)min(j0 + l15, N) * I.ldv + 4 * l4;
+  const double *pd = I.vd + 4 * l4;
+  double4_t acc;
+  const int j = j0 + l15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = i0 + l4 + 4 * r;
+    acc[r] = (i < nb && j <= i) ? I.K[(int64_t)i * I.ldk + j] : 0.0;
+  }
+  for (int k0 = 0; k0 < depth; k0 += 64) {
+    double2_t a[4][2], b[4][2], d[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k = min(k0 + 16 * c, depth - 16);  // (a clamped chunk is skipped below)
+      a[c][0] = *reinterpret_cast<const double2_t *>(pa + k);
+      a[c][1] = *reinterpret_cast<const double2_t *>(pa + k + 2);
+      b[c][0] = *reinterpret_cast<const double2_t *>(pb + k);
+      b[c][1] = *reinterpret_cast<const double2_t *>(pb + k + 2);
+      d[c][0] = *reinterpret_cast<const double2_t *>(pd + k);
+      d[c][1] = *reinterpret_cast<const double2_t *>(pd + k + 2);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (k0 + 16 * c >= depth) break;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[c][0][0] * d[c][0][0], b[c][0][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[c][0][1] * d[c][0][1], b[c][0][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[c][1][0] * d[c][1][0], b[c][1][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[c][1][1] * d[c][1][1], b[c][1][1], acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = i0 + l4 + 4 * r;
+    if (i < nb && j <= i) I.K[(int64_t)i * I.ldk + j] = acc[r];
+  }
 }
 
 // ------------------------------------------------------------------ batched wrappers
@@ -1862,7 +1905,7 @@ void ldlt_batch_launch_chain_update(hipStream_t s, const BInst *tab, int B, int 
                        std::max(per, 1), m, wbuf, c1, 0, vdepth);
 }
 void ldlt_batch_launch_virtual_diag(hipStream_t s, const BInst *tab, int B, int vdepth) {
-  hipLaunchKernelGGL(kb_virtual_diag, dim3(136, 1, B), dim3(256), 0, s, tab, vdepth);
+  hipLaunchKernelGGL(kb_virtual_diag, dim3(34, 1, B), dim3(256), 0, s, tab, vdepth);
 }
 void ldlt_batch_launch_chain(hipStream_t s, const BInst *tab, int B, int m, int c0, bool helpers) {
   const int Bp = 8 * ((B + 7) / 8);
