@@ -1785,7 +1785,11 @@ int pgf_batch_advance_outer_each(pgf_batch b, const double *dt, const double *rh
   (void)hipSetDevice(b->device);
   // the pinned staging buffers may still be in flight from the previous call
   BHIPCHK(b, hipStreamSynchronize(b->stream));
+  // g = Qx + q + A'(rho c + y) and c only change when a point moves (a rejected instance goes
+  // back to its outer point) or its rho does: otherwise what the last step evaluated ahead stays
+  bool eval_stays = b->eval_fresh;
   for (int i = 0; i < b->B; ++i) {
+    if ((accept && !accept[i]) || rho[i] != b->hs[i]->rho) eval_stays = false;
     double *p = b->h_ps + (size_t)BPS_STRIDE * i;
     const double lamb = 1.0 / dt[i];
     p[BPS_DT] = dt[i];
@@ -1826,7 +1830,7 @@ int pgf_batch_advance_outer_each(pgf_batch b, const double *dt, const double *rh
                             hipMemcpyHostToDevice, b->stream));
   BHIPCHK(b, hipMemcpyAsync(b->bytes, b->h_bytes, (size_t)b->B, hipMemcpyHostToDevice, b->stream));
   batch_launch_advance(b->stream, b->tab, b->B, b->sc, b->bytes);
-  b->eval_fresh = false;  // g depends on rho, and rejected instances moved
+  b->eval_fresh = eval_stays;  // g depends on rho, and rejected instances moved
   b->outer_set = true;
   b->have_mask = false;
   b->all_factored = false;
