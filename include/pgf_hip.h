@@ -266,6 +266,10 @@ int pgf_batch_get_masks(pgf_batch b, uint8_t *mask);
 /* pgf_qp_measures for every instance: out[count][4] */
 int pgf_batch_measures(pgf_batch b, double active_tol, double *out);
 int pgf_batch_stream(pgf_batch b, void **stream_out);
+/* Instances whose step the accuracy guard REPAIRED inside pgf_batch_sync since the batch was
+ * created: the sampled residual of the batched solve failed, and the single-instance guard on the
+ * instance's handle (full residual, refinement, pivoted LU) produced the step. */
+int pgf_batch_refinement_stats(pgf_batch b, int *repaired);
 /* as pgf_profile_enable / pgf_profile_read, for the batch's trailing-update launches */
 int pgf_batch_profile_enable(pgf_batch b, int on);
 int pgf_batch_profile_read(pgf_batch b, double *update_ms, int64_t *update_launches,

@@ -102,6 +102,7 @@ SIGNATURES = {
     "pgf_debug_fail_next_helper": (C.c_int, [_h]),
     "pgf_debug_chain_helpers": (C.c_int, [C.c_int]),
     "pgf_debug_factor_kind": (C.c_int, [_h]),
+    "pgf_batch_refinement_stats": (C.c_int, [_h, _ip]),
     "pgf_batch_debug_fail_next_helper": (C.c_int, [_h]),
 }
 

@@ -281,6 +281,16 @@ class BatchedDeviceNewton:
             batch=self._b, what="pgf_batch_ctl_read")
         return lamb, acc, log
 
+    def repaired(self):
+        """Instances whose step the accuracy guard repaired inside a batched step so far
+        (``pgf_batch_refinement_stats``): sampled residual failed, the instance's handle refined
+        or fell back to the pivoted LU."""
+        C = self._C
+        k = C.c_int(0)
+        if self._b is not None:
+            self._lib.check(self._lib.load().pgf_batch_refinement_stats(self._b, C.byref(k)), batch=self._b)
+        return k.value
+
     def profile(self, on=True):
         if self._b is not None:
             self._lib.check(self._lib.load().pgf_batch_profile_enable(self._b, int(on)),

@@ -1593,6 +1593,7 @@ struct pgf_batch_s {
   // refactorises every instance anyway and may choose
   bool cond_ok = false, cond_wanted = false, cond_last = false, cond_free = true;
   int cond_mp = 0;
+  int repaired = 0;  // instances whose step the host-side guard repaired (pgf_batch_refinement_stats)
   int inject_helper_failure = 0;  // test hook: instance 0's next factorisation reports failed helpers
   // device-resident step controller (pgf_batch_ctl_*): per-instance state, constants, and a
   // log of (lambda used, lambda next, accepted) per outer iteration and instance
@@ -2079,6 +2080,47 @@ int pgf_batch_ctl_read(pgf_batch b, double *lamb, uint8_t *accepted, double *log
   return PGF_OK;
 }
 
+// An instance whose sampled residual failed (kb_sample_residual; kb_step_update then left its point
+// alone): the single-instance accuracy guard on its handle -- full residual with K applied from H,
+// J and the mask, iterative refinement with the factor the batch made, the pivoted LU if that does
+// not contract (refine_if_needed) -- then the step update from the repaired solution.  The batch's
+// stream is idle (pgf_batch_sync); the handle's buffers ARE the instance's.  Returns 0 when the
+// instance's step is good now (its point, step length and factor state are in place).
+static int batch_repair_instance(pgf_batch b, int i, double *diff_out) {
+  pgf_handle h = b->hs[i];
+  if (h->sparse || !h->refine_mode) return PGF_SINGULAR;
+  const int nI = b->h_flags[3 * i + 2];
+  h->nI = nI;
+  h->nA = h->n - nI;
+  h->N = nI + h->m;
+  h->mask_set = true;
+  h->condensed = b->cond_last;
+  h->lu_active = false;
+  h->last_solve = 2;
+  DenseLdlt &f = h->fac;
+  f.N = h->condensed ? nI : h->N;
+  f.vdepth = h->condensed ? b->cond_mp : 0;
+  f.ldv = b->cond_mp;
+  f.vneg = h->m;
+  f.factored = true;
+  f.n_neg = b->h_flags[3 * i + 1] + (h->condensed ? h->m : 0);
+  enqueue_residual(h);
+  hipError_t e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) return hip_fail(h, e, "batched repair");
+  int rc = refine_if_needed(h, /*swapped=*/false, /*with_step=*/false);
+  if (rc) return rc;
+  enqueue_step_update(h);  // (x, y) -> (xn, yn), dx, dy, ||d||
+  launch_copy(h->stream, h->x, h->xn, h->n);
+  launch_copy(h->stream, h->y, h->yn, h->m);
+  if ((e = hipMemcpyAsync(h->h_scal, h->scal, sizeof(double), hipMemcpyDeviceToHost, h->stream)) != hipSuccess ||
+      (e = hipStreamSynchronize(h->stream)) != hipSuccess)
+    return hip_fail(h, e, "batched repair");
+  if (ldlt_chain_check(f)) return fail(h, PGF_HIP_ERROR, k_chain_msg);
+  *diff_out = h->h_scal[0];
+  invalidate_factor(h);  // host-side view only: the batch's own flag (ctl[1]) already says "refactorise"
+  return PGF_OK;
+}
+
 int pgf_batch_sync(pgf_batch b, int *status, int *n_neg, double *diff) {
   if (!b) return PGF_INVALID;
   if (!b->step_pending) return bfail(b, PGF_NOT_READY, "no step pending");
@@ -2087,6 +2129,19 @@ int pgf_batch_sync(pgf_batch b, int *status, int *n_neg, double *diff) {
   BHIPCHK(b, hipStreamSynchronize(b->stream));
   bool all_ok = true;
   for (int i = 0; i < b->B; ++i) {
+    // bit 2 alone: the factorisation went through but the sampled residual of the solve is too
+    // large (element growth): repaired on the instance's handle where the reference's pivoted LU
+    // would simply have solved -- only an instance that cannot be repaired
+    // reports a failed step
+    if (b->h_flags[3 * i] == 4) {
+      double d = 0.0;
+      if (batch_repair_instance(b, i, &d) == PGF_OK) {
+        b->h_flags[3 * i] = 0;
+        b->h_diff[i] = d;
+        b->eval_fresh = false;  // the instance moved after the evaluation made ahead
+        ++b->repaired;
+      }
+    }
     const bool bad = b->h_flags[3 * i] != 0;
     // bit 1: the instance's chain helpers failed a hand-over check (kb_step_final): the step is
     // reported like a failed factorisation -- the controllers reject and repeat it -- and the
@@ -2106,6 +2161,12 @@ int pgf_batch_sync(pgf_batch b, int *status, int *n_neg, double *diff) {
     if (diff) diff[i] = b->h_diff[i];
   }
   b->all_factored = all_ok;
+  return PGF_OK;
+}
+
+int pgf_batch_refinement_stats(pgf_batch b, int *repaired) {
+  if (!b) return PGF_INVALID;
+  if (repaired) *repaired = b->repaired;
   return PGF_OK;
 }
 

@@ -1041,7 +1041,10 @@ __global__ __launch_bounds__(256) void kb_step_update(const BInst *__restrict__ 
   if (I.ctl[3]) return;
   b_step_update(n, m, I.counts[0], I.ps[BPS_FACT], I.ps[BPS_RHO], I.x, I.y, I.lb, I.ub, I.mask, I.pos, I.b0full, I.F,
                 I.sol, I.dx, I.dy, I.xn, I.yn, I.red);
-  // the new point replaces the current one in place (each lane re-reads its own entry)
+  // the new point replaces the current one in place (each lane re-reads its own entry) -- unless
+  // the sampled residual of the solve failed: the host repairs such an instance from the point it
+  // started at (batch_repair_instance, pgf_api.hip)
+  if (I.flags[3]) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n)
     I.x[i] = I.xn[i];
