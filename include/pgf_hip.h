@@ -270,6 +270,24 @@ int pgf_batch_stream(pgf_batch b, void **stream_out);
  * created: the sampled residual of the batched solve failed, and the single-instance guard on the
  * instance's handle (full residual, refinement, pivoted LU) produced the step. */
 int pgf_batch_refinement_stats(pgf_batch b, int *repaired);
+/* ---- the batched mode's one collective, without Python ----------------
+ * One process per GPU; every rank advances its shard of the instances as a device batch and the
+ * residual norms of ALL instances are all-gathered once per step (the reference gathers per-
+ * instance results from its process pool, runners/runner.py:107-153).  pygradflow_amd/batched.py
+ * does this through torch.distributed (backend "nccl" = RCCL); these entry points do the same for
+ * a host without PyTorch: librccl.so is opened at run time (dlopen; the library has no link-time
+ * dependency on it), rank 0 creates the 128-byte id and hands it to the other ranks by whatever
+ * means the host has, every rank creates its communicator on its own device.
+ * pgf_batch_allgather_norms: ||F|| of the batch's current points (as pgf_batch_residual_norms)
+ * into slot `rank' of all_dev -- a DEVICE array of nranks * count doubles -- and one
+ * ncclAllGather on the batch's stream; returns after the stream has drained.  Every rank must
+ * hold the same number of instances.  PGF_NOT_READY if librccl.so cannot be loaded. */
+typedef struct pgf_comm_s *pgf_comm;
+#define PGF_COMM_ID_BYTES 128
+int pgf_comm_unique_id(void *id_out);
+int pgf_comm_create(int nranks, int rank, const void *id, int device, pgf_comm *out);
+int pgf_comm_destroy(pgf_comm c);
+int pgf_batch_allgather_norms(pgf_batch b, pgf_comm c, double *all_dev);
 /* as pgf_profile_enable / pgf_profile_read, for the batch's trailing-update launches */
 int pgf_batch_profile_enable(pgf_batch b, int on);
 int pgf_batch_profile_read(pgf_batch b, double *update_ms, int64_t *update_launches,

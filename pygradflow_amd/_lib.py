@@ -103,6 +103,10 @@ SIGNATURES = {
     "pgf_debug_chain_helpers": (C.c_int, [C.c_int]),
     "pgf_debug_factor_kind": (C.c_int, [_h]),
     "pgf_batch_refinement_stats": (C.c_int, [_h, _ip]),
+    "pgf_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "pgf_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "pgf_comm_destroy": (C.c_int, [C.c_void_p]),
+    "pgf_batch_allgather_norms": (C.c_int, [_h, C.c_void_p, C.c_void_p]),
     "pgf_batch_debug_fail_next_helper": (C.c_int, [_h]),
 }
 

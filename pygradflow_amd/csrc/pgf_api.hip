@@ -2164,6 +2164,95 @@ int pgf_batch_sync(pgf_batch b, int *status, int *n_neg, double *diff) {
   return PGF_OK;
 }
 
+// ---- RCCL without PyTorch: the all-gather of residual norms as a C entry point ---------------
+// (librccl.so through dlopen: a process that already runs torch.distributed keeps ITS copy of the
+// library, and a host that never gathers never loads one)
+#include <dlfcn.h>
+namespace {
+struct RcclApi {
+  void *lib = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;
+  // ncclUniqueId is passed BY VALUE: a 128-byte struct
+  struct Id {
+    char b[PGF_COMM_ID_BYTES];
+  };
+  int (*CommInitRank)(void **, int, Id, int) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  bool ok = false;
+};
+RcclApi &rccl() {
+  static RcclApi a = []() {
+    RcclApi r;
+    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) return r;
+    r.GetUniqueId = (int (*)(void *))dlsym(r.lib, "ncclGetUniqueId");
+    r.CommInitRank = (int (*)(void **, int, RcclApi::Id, int))dlsym(r.lib, "ncclCommInitRank");
+    r.CommDestroy = (int (*)(void *))dlsym(r.lib, "ncclCommDestroy");
+    r.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(r.lib, "ncclAllGather");
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather;
+    return r;
+  }();
+  return a;
+}
+}  // namespace
+struct pgf_comm_s {
+  void *comm = nullptr;
+  int nranks = 0, rank = 0, device = 0;
+};
+
+int pgf_comm_unique_id(void *id_out) {
+  if (!id_out) return PGF_INVALID;
+  if (!rccl().ok) return PGF_NOT_READY;
+  return rccl().GetUniqueId(id_out) == 0 ? PGF_OK : PGF_HIP_ERROR;
+}
+
+int pgf_comm_create(int nranks, int rank, const void *id, int device, pgf_comm *out) {
+  if (!out || !id || nranks <= 0 || rank < 0 || rank >= nranks) return PGF_INVALID;
+  if (!rccl().ok) return PGF_NOT_READY;
+  if (hipSetDevice(device) != hipSuccess) return PGF_INVALID;
+  pgf_comm c = new (std::nothrow) pgf_comm_s();
+  if (!c) return PGF_HIP_ERROR;
+  RcclApi::Id uid;
+  std::memcpy(uid.b, id, PGF_COMM_ID_BYTES);
+  if (rccl().CommInitRank(&c->comm, nranks, uid, rank) != 0) {
+    delete c;
+    return PGF_HIP_ERROR;
+  }
+  c->nranks = nranks;
+  c->rank = rank;
+  c->device = device;
+  *out = c;
+  return PGF_OK;
+}
+
+int pgf_comm_destroy(pgf_comm c) {
+  if (!c) return PGF_OK;
+  if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
+  delete c;
+  return PGF_OK;
+}
+
+int pgf_batch_allgather_norms(pgf_batch b, pgf_comm c, double *all_dev) {
+  if (!b || !c || !all_dev) return PGF_INVALID;
+  if (!b->outer_set) return bfail(b, PGF_NOT_READY, "pgf_batch_advance_outer first");
+  if (b->step_pending) return bfail(b, PGF_NOT_READY, "pgf_batch_sync the previous step first");
+  if (c->device != b->device) return bfail(b, PGF_INVALID, "communicator and batch live on different devices");
+  (void)hipSetDevice(b->device);
+  batch_eval(b);
+  batch_launch_res_norm(b->stream, b->tab, b->B, b->sc, b->norm_out);
+  double *slot = all_dev + (size_t)c->rank * b->B;
+  BHIPCHK(b, hipMemcpyAsync(slot, b->norm_out, b->B * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+  // in place: every rank's send buffer is its own slot of the receive buffer (ncclFloat64 = 8)
+  if (rccl().AllGather(slot, all_dev, (size_t)b->B, /*ncclFloat64*/ 8, c->comm, b->stream) != 0)
+    return bfail(b, PGF_HIP_ERROR, "ncclAllGather failed");
+  BHIPCHK(b, hipStreamSynchronize(b->stream));
+  return PGF_OK;
+}
+
 int pgf_batch_refinement_stats(pgf_batch b, int *repaired) {
   if (!b) return PGF_INVALID;
   if (repaired) *repaired = b->repaired;

@@ -1123,6 +1123,41 @@ def test_batched_unstable_pivot_is_repaired_for_that_instance(pgf, eps):
     bd.close()
 
 
+def test_rccl_allgather_entry_point_single_rank(pgf):
+    """pgf_comm_* / pgf_batch_allgather_norms (include/pgf_hip.h): the batched mode's one collective
+    as a C entry point -- librccl opened at run time, no PyTorch in the call.  One rank is all a
+    one-GPU box can hold (RCCL refuses two ranks on one device): communicator of size 1, the
+    gathered norms equal pgf_batch_residual_norms; the multi-rank shape of the call is the same
+    in-place all-gather that pygradflow_amd/batched.py issues through torch.distributed and
+    tests/test_batched_gloo.py covers with two ranks."""
+    import ctypes as C
+
+    import torch
+
+    from pygradflow_amd import _lib, problems
+    from pygradflow_amd.batched import BatchedDeviceNewton
+
+    lib = _lib.load()
+    n, m, B = 48, 12, 3
+    bd = BatchedDeviceNewton(lambda i: problems.dense_qp(n, m, seed=60 + i, boxed_frac=0.2, box=0.05), B,
+                             "Full", 1.0, 1.0)
+    bd.step_local()
+    uid = (C.c_char * 128)()
+    rc = lib.pgf_comm_unique_id(C.cast(uid, C.c_void_p))
+    if rc == _lib.PGF_NOT_READY:
+        pytest.skip("librccl.so not loadable on this box")
+    assert rc == 0
+    comm = C.c_void_p()
+    assert lib.pgf_comm_create(1, 0, C.cast(uid, C.c_void_p), 0, C.byref(comm)) == 0
+    out = torch.full((B,), -1.0, dtype=torch.float64, device="cuda:0")
+    assert lib.pgf_batch_allgather_norms(bd._b, comm, C.c_void_p(out.data_ptr())) == 0
+    ref = np.empty(B)
+    assert lib.pgf_batch_residual_norms(bd._b, _lib.dptr(ref), None) == 0
+    assert np.array_equal(out.cpu().numpy(), ref) and (ref > 0).all()
+    assert lib.pgf_comm_destroy(comm) == 0
+    bd.close()
+
+
 def test_modified_problem_is_uploaded_again(pgf):
     """HBM residency of constant H, J is keyed on the problem object AND the state of its data
     (ADVICE r1 / r2): new matrices -- here ONE off-diagonal entry pair, which the strided sample
