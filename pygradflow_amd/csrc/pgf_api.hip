@@ -74,6 +74,7 @@ struct pgf_solver {
   bool sp_stat_pending = false;  // a guarded banded step's status block is on its way to h_bred
   // the current dense factor is that of the condensed system (constraint block eliminated
   // first, condensed_wanted below); cd_t: its right-hand side
+  bool fused_eval_done = false;  // newton_core_async evaluated g, c at (xn, yn) beside the residual check
   bool condensed = false;
   bool condensed_veto = false;  // it met a zero pivot: natural order until the matrix changes
   double *cd_t = nullptr;
@@ -170,7 +171,8 @@ int pgf_create(int n, int m, int device, unsigned flags, pgf_handle *out) {
   A_(lb, n) A_(ub, n) A_(slb, n) A_(sub, n) A_(xhat, n) A_(yhat, m);
   A_(x, n) A_(y, m) A_(xn, n) A_(yn, m) A_(g, n) A_(c, m) A_(F, N) A_(b0full, n);
   A_(rhs, N + 1) A_(sol, N + 1) A_(dx, n) A_(dy, m);
-  A_(q, n) A_(b, m) A_(w, m) A_(tmpn, n) A_(partial, (size_t)PGF_GEMVT_PARTS * (n ? n : 1));
+  // (partial: two sets of PGF_GEMVT_PARTS row chunks of n: launch_residual_and_eval carries two vectors)
+  A_(q, n) A_(b, m) A_(w, m) A_(tmpn, n) A_(partial, (size_t)2 * PGF_GEMVT_PARTS * (n ? n : 1));
   A_(red, (N + 255) / 256 + 1) A_(scal, 4) A_(meas, 4 * ((N + 255) / 256) + 4);
   if (!sparse) {
     A_(rs_v, n) A_(rs_lv, n) A_(rs_u, n) A_(rs_wy, m) A_(rs_r, N + 1) A_(rs_d, N + 1) A_(rs_red, 8);
@@ -999,6 +1001,23 @@ static int newton_core_async(pgf_handle h, bool *did_factor) {
     else
       HIPCHK(h, kkt_solve_async(h, h->rhs, h->sol));
   }
+  // Device-resident mode: the residual check of this solve and g, c at the point the step update
+  // produces read the same matrices -- one pass over H and two over J for both
+  // (launch_residual_and_eval) instead of two and four.  (PGF_EVAL_AHEAD=0: separately, the
+  // evaluation at the start of the next step.)
+  static const bool ahead = !(getenv("PGF_EVAL_AHEAD") && atoi(getenv("PGF_EVAL_AHEAD")) == 0);
+  h->fused_eval_done = false;
+  h->rs_skipped = !*did_factor && h->factor_clean;
+  if (ahead && h->qp_mode && h->refine_mode && !h->rs_skipped) {
+    enqueue_step_update(h);
+    launch_residual_and_eval(s, h->n, h->m, h->nI, h->lamb, h->delta, h->H, h->ldh, h->J, h->ldj, h->idxI,
+                             h->pos, h->mask, h->rhs, h->sol, h->rs_v, h->rs_lv, h->rs_u, h->rs_wy, h->partial,
+                             PGF_GEMVT_PARTS, h->rs_r, h->rs_red, h->xn, h->yn, h->b, h->q, h->rho, h->c, h->w,
+                             h->tmpn, h->g);
+    (void)hipMemcpyAsync(h->h_rs, h->rs_red, 3 * sizeof(double), hipMemcpyDeviceToHost, s);
+    h->fused_eval_done = true;
+    return PGF_OK;
+  }
   enqueue_residual(h, !*did_factor);
   enqueue_step_update(h);
   return PGF_OK;
@@ -1459,7 +1478,12 @@ int pgf_qp_step_async(pgf_handle h, unsigned policy, double tau) {
   // (~35 us of gaps at config 2).  Whatever moves the point afterwards (refinement, a repeated
   // step, pgf_qp_set_point, a new rho) clears eval_fresh again.
   static const bool ahead = !(getenv("PGF_EVAL_AHEAD") && atoi(getenv("PGF_EVAL_AHEAD")) == 0);
-  if (ahead && !h->sparse) qp_eval(h);
+  if (h->fused_eval_done) {  // (newton_core_async did it beside the residual check)
+    h->eval_fresh = true;
+    h->fused_eval_done = false;
+  } else if (ahead && !h->sparse) {
+    qp_eval(h);
+  }
   if (!h->sp_stat_pending && (rc = down(h, h->h_scal, h->scal, sizeof(double)))) return rc;
   h->step_pending = true;
   return PGF_OK;

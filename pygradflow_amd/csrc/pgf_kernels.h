@@ -68,3 +68,11 @@ void launch_cond_rhs(hipStream_t s, int nI, int m, const double *V, int64_t ldv,
 // sol_y <- (V^T sol_x - rhs_y) / delta
 void launch_cond_y(hipStream_t s, int nI, int m, const double *V, int64_t ldv, const double *solx,
                    const double *rhs_y, double delta, double *partial, size_t partial_cap, double *sol_y);
+// launch_kkt_residual of the solve just made AND the evaluation of g, c at the new point (xn, yn)
+// in one pass over H and two over J (the separate kernels: two and four); partial: 2 * nparts * n
+void launch_residual_and_eval(hipStream_t s, int n, int m, int nI, double lamb, double delta, const double *H,
+                              int64_t ldh, const double *J, int64_t ldj, const int *idxI, const int *pos,
+                              const uint8_t *mask, const double *rhs, const double *sol, double *v, double *lv,
+                              double *u, double *wy, double *partial, int nparts, double *r, double *red3,
+                              const double *xn, const double *yn, const double *b, const double *q, double rho,
+                              double *c, double *w, double *tmpn, double *g);

@@ -839,6 +839,129 @@ void launch_kkt_residual(hipStream_t s, int n, int m, int nI, double lamb, doubl
                      reinterpret_cast<unsigned long long *>(red3));
 }
 
+// ---- residual check of this step's solve AND g, c at the new point in one pass over H and J ----
+// The check applies K from H, J and the mask to the solution; the next step's evaluation applies
+// the same matrices to the new point: streamed separately they read H once and J twice EACH
+// (336 MB at config 2).  Two right-hand vectors per matrix pass instead: every dot product is the
+// row_dot / b_gemvT_partial arithmetic of the separate kernels, in the same order (bit-identical
+// g, c and residual), the matrices are read once.
+__device__ __forceinline__ void row_dot2(const double *__restrict__ row, const double *__restrict__ v1,
+                                         const double *__restrict__ v2, int cols, int lane, double &d1,
+                                         double &d2) {
+  double a1 = 0.0, a2 = 0.0;
+  int j = lane * 2;
+  if ((((uintptr_t)row) & 15) == 0) {
+    for (; j + 1 < cols; j += 128) {
+      const double2 a = *reinterpret_cast<const double2 *>(row + j);
+      const double2 b1 = *reinterpret_cast<const double2 *>(v1 + j);
+      const double2 b2 = *reinterpret_cast<const double2 *>(v2 + j);
+      a1 = fma(a.x, b1.x, a1);
+      a1 = fma(a.y, b1.y, a1);
+      a2 = fma(a.x, b2.x, a2);
+      a2 = fma(a.y, b2.y, a2);
+    }
+    if (j < cols) {
+      a1 = fma(row[j], v1[j], a1);
+      a2 = fma(row[j], v2[j], a2);
+    }
+  } else {
+    for (j = lane; j < cols; j += 64) {
+      a1 = fma(row[j], v1[j], a1);
+      a2 = fma(row[j], v2[j], a2);
+    }
+  }
+  d1 = wave_sum(a1);
+  d2 = wave_sum(a2);
+}
+// out1 = M v1 + sgn1 add1, out2 = M v2 + sgn2 add2 (b_gemv_rows twice, one read of M)
+__global__ __launch_bounds__(256) void k_gemv_rows2(int rows, int cols, const double *__restrict__ M, int64_t ld,
+                                                    const double *__restrict__ v1, const double *__restrict__ add1,
+                                                    double sgn1, double *__restrict__ out1,
+                                                    const double *__restrict__ v2, const double *__restrict__ add2,
+                                                    double sgn2, double *__restrict__ out2) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  double d1, d2;
+  row_dot2(M + (int64_t)r * ld, v1, v2, cols, lane, d1, d2);
+  if (lane == 0) {
+    out1[r] = d1 + sgn1 * add1[r];
+    out2[r] = d2 + sgn2 * add2[r];
+  }
+}
+// partial1[rb][j] = sum_{r in chunk rb} M[r][j] w1[r], partial2 likewise with w2
+__global__ __launch_bounds__(256) void k_gemvT_partial2(int rows, int cols, const double *__restrict__ M,
+                                                        int64_t ld, const double *__restrict__ w1,
+                                                        const double *__restrict__ w2, int chunk,
+                                                        double *__restrict__ partial1,
+                                                        double *__restrict__ partial2) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= cols) return;
+  const int r0 = blockIdx.y * chunk;
+  const int r1 = min(rows, r0 + chunk);
+  double a1 = 0.0, a2 = 0.0;
+  for (int r = r0; r < r1; ++r) {
+    const double mv = M[(int64_t)r * ld + j];
+    a1 = fma(mv, w1[r], a1);
+    a2 = fma(mv, w2[r], a2);
+  }
+  partial1[(int64_t)blockIdx.y * cols + j] = a1;
+  partial2[(int64_t)blockIdx.y * cols + j] = a2;
+}
+__global__ void k_sum_partials2(int cols, int nparts, const double *__restrict__ partial1,
+                                const double *__restrict__ base1, double *__restrict__ out1,
+                                const double *__restrict__ partial2, const double *__restrict__ base2,
+                                double *__restrict__ out2) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cols) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int p = 0; p < nparts; ++p) {
+    s1 += partial1[(int64_t)p * cols + j];
+    s2 += partial2[(int64_t)p * cols + j];
+  }
+  out1[j] = base1[j] + s1;
+  out2[j] = base2[j] + s2;
+}
+
+// launch_kkt_residual (solution sol of the system rhs; r, red3 as there) and the evaluation
+//   c = J xn - b ; w = rho c + yn ; tmpn = q + J' w ; g = H xn + tmpn
+// at the point (xn, yn) the step update has just produced.  partial: 2 * nparts * n doubles.
+void launch_residual_and_eval(hipStream_t s, int n, int m, int nI, double lamb, double delta, const double *H,
+                              int64_t ldh, const double *J, int64_t ldj, const int *idxI, const int *pos,
+                              const uint8_t *mask, const double *rhs, const double *sol, double *v, double *lv,
+                              double *u, double *wy, double *partial, int nparts, double *r, double *red3,
+                              const double *xn, const double *yn, const double *b, const double *q, double rho,
+                              double *c, double *w, double *tmpn, double *g) {
+  const int N = nI + m;
+  (void)hipMemsetAsync(red3, 0, 3 * sizeof(double), s);
+  if (n) hipLaunchKernelGGL(k_expand_sol, g1(n), dim3(256), 0, s, n, nI, pos, mask, sol, lamb, v, lv);
+  // one pass over J: c = J xn - b, wy = J v - delta s_y
+  if (m)
+    hipLaunchKernelGGL(k_gemv_rows2, dim3((m + 3) / 4), dim3(256), 0, s, m, n, J, ldj, xn, b, -1.0, c, v,
+                       sol + nI, -delta, wy);
+  launch_mult_vec(s, m, rho, c, yn, w);
+  // one pass over J (transposed): tmpn = q + J' w, u = lambda v + J' s_y
+  if (n) {
+    if (m == 0) {
+      launch_copy(s, tmpn, q, n);
+      launch_copy(s, u, lv, n);
+    } else {
+      const int chunk = (m + nparts - 1) / nparts;
+      const int used = (m + chunk - 1) / chunk;
+      double *p2 = partial + (size_t)nparts * n;
+      hipLaunchKernelGGL(k_gemvT_partial2, dim3((n + 255) / 256, used), dim3(256), 0, s, m, n, J, ldj, w,
+                         sol + nI, chunk, partial, p2);
+      hipLaunchKernelGGL(k_sum_partials2, g1(n), dim3(256), 0, s, n, used, partial, q, tmpn, p2, lv, u);
+    }
+    // one pass over H: g = H xn + tmpn, lv <- H v + u
+    hipLaunchKernelGGL(k_gemv_rows2, dim3((n + 3) / 4), dim3(256), 0, s, n, n, H, ldh, xn, tmpn, 1.0, g, v, u,
+                       1.0, lv);
+  }
+  if (N)
+    hipLaunchKernelGGL(k_kkt_residual, g1(N), dim3(256), 0, s, N, nI, idxI, rhs, sol, lv, wy, r,
+                       reinterpret_cast<unsigned long long *>(red3));
+}
+
 // ---- matrix norms for the normwise backward error of the residual guard (pgf_api.hip)
 // out[0] = max_i sum_j |A_ij| (rows x cols, row-major): one workgroup per row; non-negative
 // doubles order like their bit patterns, so atomicMax on the 64-bit words does the reduction
