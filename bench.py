@@ -451,9 +451,23 @@ def main():
         dn.profile(True)
     for i in range(args.steps):
         one_step(i)
+    pr = pp = None
     if rank == 0:
         pr = dn.profile_read()
         dn.profile(False)
+    if not is_sparse:
+        # the PRODUCTION launches: a second instrumented pass, one span per launch -- walked by
+        # every rank as well (a step ends in the all-gather: rank 0 alone would leave the others
+        # behind in a different collective)
+        dn.set_outer(x0, y0, 1.0, 1.0)
+        if rank == 0:
+            dn.profile(2)
+        for i in range(args.steps):
+            one_step(i)
+        if rank == 0:
+            pp = dn.profile_read()
+            dn.profile(False)
+    if rank == 0:
         if is_sparse and pr["update_launches"] > 0 and pr["update_ms"] > 0:
             # banded path: the dominant piece is the block-cyclic-reduction solve (one span =
             # extract + log2(N/8) invert/reduce levels + the back-substitution levels); the
@@ -497,14 +511,7 @@ def main():
                       "the trailing update share one launch (k_chain_update: same tile code, "
                       "same job table), T(k) and the next diagonal block's update another "
                       "(k_trsm_ud)"))
-            # the PRODUCTION launches: a second instrumented pass, one span per launch
-            dn.set_outer(x0, y0, 1.0, 1.0)
-            dn.profile(2)
-            for i in range(args.steps):
-                one_step(i)
-            pp = dn.profile_read()
-            dn.profile(False)
-            fused_ok = pp["fused_launches"] > 0 and pp["fused_ms"] > 0
+            fused_ok = pp is not None and pp["fused_launches"] > 0 and pp["fused_ms"] > 0
             achieved = (pp["fused_flops"] / (pp["fused_ms"] * 1e-3) / 1e12) if fused_ok else achieved_u
             traffic = (pmc_traffic("k_chain_update")
                        if args.workload == "dense_qp_n4096_m1024" and fused_ok else None)
