@@ -1,5 +1,13 @@
-// The diagonal chain D(k), third design (default; replaces the LDS-panel chain of
-// pgf_factor2.hip's chain_body, which stays behind PGF_CHAIN=2 as the cross-check).
+// The diagonal chain D(k), third design -- EXPERIMENTAL, NOT the default (PGF_CHAIN=3 selects it;
+// the production chain is chain_body of pgf_factor2.hip).  Correct for every block size
+// (tools/chain3_test.hip, tests/test_gpu_schedules.py variant "register_resident_chain"), but
+// 78-92 us per block against 64 us for the LDS-panel chain with DPP elimination: the rank-16 MFMA
+// work of one block is bound by ONE CU's matrix pipes whatever the layout, MFMAs and the
+// elimination's VALU work contend whenever they share a SIMD, and the operand traffic through LDS
+// comes back as the critical section.  Kept as the record of that experiment and
+// of the hardware measurements at the end of this comment; the description below is the design
+// as built (three role loops: elimination wavefront 0, service wavefronts 4 / 8 / 12 for the
+// write-backs, twelve owner wavefronts on SIMDs 1-3 with lagged rank-16 updates).
 //
 // LDL^T of one 256 x 256 diagonal block of the reduced KKT matrix by ONE 16-wavefront
 // workgroup: the factorisation's serial pivot chain (reference: SuperLU gstrf behind
