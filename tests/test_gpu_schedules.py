@@ -101,6 +101,24 @@ def test_condensed_factorisation_matches_oracle(gpu_available, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed,condensed", [(0, "2"), (1, "2"), (2, "0"), (3, "1")])
+def test_random_shapes_against_oracle(gpu_available, seed, condensed):
+    """tools/check_random.py: 24 boxed dense QPs of random shape (n around the 256-column block
+    boundaries, m from 0 to 600, boxed share, box width, dt from 0.1 to 1000, rho, policy) through
+    DeviceNewton against the CPU oracle: masks bit for bit, iterates to 1e-10, inertia m, never the
+    LU -- with the condensed pivot order wherever its bounds allow (PGF_CONDENSED=2), never (0) and
+    by the default rule (1)."""
+    if not gpu_available:
+        pytest.skip("needs a GPU")
+    env = dict(os.environ)
+    env["PGF_CONDENSED"] = condensed
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "check_random.py"), str(seed), "24"],
+                         env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "random ok" in out.stdout
+
+
+@pytest.mark.gpu
 def test_golden_replays_in_the_condensed_order(gpu_available):
     """The reference's recorded steps once more with the constraint block eliminated first wherever
     the growth bound allows (PGF_CONDENSED=2; the default mode only picks it from m = 64 and a saved
