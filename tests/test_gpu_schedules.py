@@ -119,6 +119,21 @@ def test_random_shapes_against_oracle(gpu_available, seed, condensed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed,condensed", [(0, "2"), (1, "2"), (0, "0")])
+def test_random_batches_against_one_by_one(gpu_available, seed, condensed):
+    """tools/check_batch_random.py: device batches of random shape and size with per-instance dt and
+    rho, rejected instances and all three policies against the same instances driven one by one."""
+    if not gpu_available:
+        pytest.skip("needs a GPU")
+    env = dict(os.environ)
+    env["PGF_CONDENSED"] = condensed
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "check_batch_random.py"), str(seed)],
+                         env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "batch random ok" in out.stdout
+
+
+@pytest.mark.gpu
 def test_golden_replays_in_the_condensed_order(gpu_available):
     """The reference's recorded steps once more with the constraint block eliminated first wherever
     the growth bound allows (PGF_CONDENSED=2; the default mode only picks it from m = 64 and a saved
