@@ -545,10 +545,17 @@ static bool condensed_wanted(pgf_handle h) {
   if (residual_norms(h)) return false;
   return condensed_growth_ok(h);
 }
+// row stride of the panel V: its depth rounded up to 32, plus 16 doubles -- at m = 1024 an 8 KB
+// stride would put the 64 / 128 rows a tile stages on the same HBM channels (as pick_ldk for K)
+static int64_t condensed_ldv(int m) {
+  const int mp = (m + 31) / 32 * 32;
+  static const bool pad = !(getenv("PGF_VPAD") && atoi(getenv("PGF_VPAD")) == 0);
+  return pad ? mp + 16 : mp;
+}
 static hipError_t condensed_reserve(pgf_handle h) {
   DenseLdlt &f = h->fac;
   const int mp = (h->m + 31) / 32 * 32;
-  const size_t need = (size_t)(h->n + 1) * mp;
+  const size_t need = (size_t)(h->n + 1) * condensed_ldv(h->m);
   hipError_t e = hipSuccess;
   if (f.vcap < need) {
     if (f.V) (void)hipFree(f.V);
@@ -615,7 +622,7 @@ static int factor_async(pgf_handle h, bool with_rhs) {
     DenseLdlt &f = h->fac;
     HIPCHK(h, condensed_reserve(h));
     const int nI = h->nI, mp = (h->m + 31) / 32 * 32;
-    f.ldv = mp;
+    f.ldv = condensed_ldv(h->m);
     f.vdepth = mp;
     f.vneg = h->m;  // the eliminated block is -delta I
     // A = H[I,I] + lamb I (the assembly kernel with no constraint rows), V = J_I^T, b_y in row nI
@@ -1763,7 +1770,7 @@ int pgf_batch_create(const pgf_handle *handles, int count, pgf_batch *out) {
       }
       t.V = h->fac.V;
       t.vd = h->fac.vd;
-      t.ldv = (h->m + 31) / 32 * 32;
+      t.ldv = condensed_ldv(h->m);
     }
     // the batch owns the device-side state of the handle from here on
     h->mask_set = false;
@@ -2124,7 +2131,7 @@ static int batch_repair_instance(pgf_batch b, int i, double *diff_out) {
   DenseLdlt &f = h->fac;
   f.N = h->condensed ? nI : h->N;
   f.vdepth = h->condensed ? b->cond_mp : 0;
-  f.ldv = b->cond_mp;
+  f.ldv = condensed_ldv(h->m);
   f.vneg = h->m;
   f.factored = true;
   f.n_neg = b->h_flags[3 * i + 1] + (h->condensed ? h->m : 0);
