@@ -1,6 +1,14 @@
-import cProfile, pstats, sys, time
+"""cProfile of Full Newton steps of BASELINE config 2 through the plug-in boundary (HipStepSolver
+under newton_method): where the host time of the drop-in path goes."""
+import cProfile
+import os
+import pstats
+import sys
+import time
+
 import numpy as np
-sys.path.insert(0, '/root/repo')
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pygradflow_amd as pgf
 from pygradflow_amd import problems
 n, m = 4096, 1024
